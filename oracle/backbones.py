@@ -1,0 +1,130 @@
+"""Oracle image backbones (torch CPU, fp32).  TEST INFRASTRUCTURE ONLY.
+
+Restates the third-party architectures the reference names in
+loadImageModelClassifier.py:50-75 (``custom-cnn``, ``resnet-18``,
+``resnet-50``).  ``custom-cnn`` is pinned by the reference import
+(it is defined in the reference itself, :50-60); the torchvision ones are
+PARITY UNPINNED (torchvision==0.19.1 is absent) and follow the published v1.5
+layout: stride on the 3x3 of the bottleneck, BN eps 1e-5 / momentum 0.1,
+kaiming_normal_(fan_out, relu) conv init, BN weight 1 / bias 0.
+Sub-module names reproduce torchvision's so ``image_encoder.*`` state_dict keys
+line up with checkpoints trained by the reference.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Stage(nn.Sequential):
+    pass
+
+
+class _Residual(nn.Module):
+    """One residual unit; `plan` is a list of (cin, cout, k, stride) convs."""
+
+    def __init__(self, plan, shortcut):
+        super().__init__()
+        for i, (cin, cout, k, s) in enumerate(plan, start=1):
+            setattr(self, f"conv{i}", nn.Conv2d(cin, cout, k, stride=s, padding=k // 2, bias=False))
+            setattr(self, f"bn{i}", nn.BatchNorm2d(cout))
+        self.nconv = len(plan)
+        if shortcut is not None:
+            cin, cout, s = shortcut
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride=s, bias=False), nn.BatchNorm2d(cout))
+        else:
+            self.downsample = None
+
+    def forward(self, x):
+        y = x
+        for i in range(1, self.nconv + 1):
+            y = getattr(self, f"bn{i}")(getattr(self, f"conv{i}")(y))
+            if i < self.nconv:
+                y = F.relu(y)
+        skip = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + skip)
+
+
+RESNET_SPECS = {
+    # name: (bottleneck?, blocks per stage)
+    "resnet-18": (False, (2, 2, 2, 2)),
+    "resnet-50": (True, (3, 4, 6, 3)),
+}
+
+
+class OracleResNet(nn.Module):
+    def __init__(self, name):
+        super().__init__()
+        bottleneck, depths = RESNET_SPECS[name]
+        expansion = 4 if bottleneck else 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = 64
+        for li, (width, nblk) in enumerate(zip((64, 128, 256, 512), depths), start=1):
+            units = []
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 1) else 1
+                cout = width * expansion
+                if bottleneck:
+                    plan = [(cin, width, 1, 1), (width, width, 3, stride), (width, cout, 1, 1)]
+                else:
+                    plan = [(cin, width, 3, stride), (width, cout, 3, 1)]
+                shortcut = (cin, cout, stride) if (stride != 1 or cin != cout) else None
+                units.append(_Residual(plan, shortcut))
+                cin = cout
+            setattr(self, f"layer{li}", _Stage(*units))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Identity()
+        self.num_features = cin
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = self.maxpool(F.relu(self.bn1(self.conv1(x))))
+        for li in range(1, 5):
+            x = getattr(self, f"layer{li}")(x)
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def custom_cnn(common_dim):
+    """loadImageModelClassifier.py:50-60."""
+    return nn.Sequential(
+        nn.Conv2d(3, 16, kernel_size=3, stride=2, padding=1),
+        nn.ReLU(),
+        nn.MaxPool2d(kernel_size=2),
+        nn.AdaptiveAvgPool2d((1, 1)),
+        nn.Flatten(),
+        nn.Linear(16, common_dim),
+    )
+
+
+def apply_train_mode(model, mode, last_n_layers=1):
+    """loadImageModelClassifier.py:15-35 (freeze policy)."""
+    params = list(model.parameters())
+    for p in params:
+        p.requires_grad = False
+    if mode == "frozen_weights":
+        return
+    if mode == "unfrozen_weights":
+        for p in params:
+            p.requires_grad = True
+    elif mode == "last_layer_unfrozen_weights":
+        for p in params[-2 * last_n_layers:]:
+            p.requires_grad = True
+    else:
+        raise ValueError(f"Invalid backbone_train_mode: {mode}")
+
+
+def build_image_encoder(name, common_dim, mode):
+    """-> (module, feature_dim); loadImageModelClassifier.py:41-157."""
+    if name == "custom-cnn":
+        net, dim = custom_cnn(common_dim), common_dim
+    elif name in RESNET_SPECS:
+        net = OracleResNet(name)
+        dim = net.num_features
+    else:
+        raise ValueError(f"Backbone '{name}' não implementado.")
+    apply_train_mode(net, mode)
+    return net, dim

@@ -1,0 +1,70 @@
+"""CPU: the oracle restatement vs fixtures generated from the real reference."""
+import pytest
+import torch
+
+from helpers import SMALL, check_record_against_golden, golden, summarize, assert_summary_close, train_step_record
+from oracle.blocks import OracleGatedResidual, OracleMetaBlock, OracleTabTransformer
+from oracle.detinit import det_init_, det_inputs, det_tensor
+from oracle.model import FUSION_STRINGS, OracleMultimodalModel
+
+RTOL, ATOL = 1e-4, 1e-6   # fp32 CPU vs fp32 CPU, different op order only
+
+
+@pytest.mark.parametrize("mech", FUSION_STRINGS)
+def test_mechanism_matches_reference(mech):
+    gold = golden("mechanisms")[mech]
+    model = det_init_(OracleMultimodalModel(**dict(SMALL, attention_mecanism=mech,
+                                                   n=1 if mech == "no-metadata" else 2)))
+    rec = train_step_record(model, *det_inputs(4, 32, 20, 6))
+    check_record_against_golden(rec, gold, RTOL, ATOL)
+
+
+def test_unknown_mechanism_error_string():
+    want = golden("mechanisms")["__error__metablock-se"]
+    model = OracleMultimodalModel(**dict(SMALL, attention_mecanism="metablock-se"))
+    with pytest.raises(ValueError) as e:
+        model(*det_inputs(4, 32, 20, 6)[:2])
+    assert str(e.value) == want
+
+
+def test_full_width_head():
+    gold = golden("full_width")
+    model = det_init_(OracleMultimodalModel(**dict(SMALL, common_dim=512, text_encoder_dim_output=512,
+                                                   attention_mecanism="crossattention")))
+    rec = train_step_record(model, *det_inputs(4, 32, 20, 6))
+    check_record_against_golden(rec, gold, RTOL, ATOL)
+
+
+def test_seed_equivalence_with_reference():
+    gold = golden("seed_equivalence")
+    torch.manual_seed(1234)
+    m = OracleMultimodalModel(**dict(SMALL, attention_mecanism="crossattention"))
+    sd = m.state_dict()
+    assert list(sd.keys()) == gold["keys"]
+    for k, s in gold["sums"].items():
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-6 * max(1.0, abs(s)), k
+
+
+def test_blocks():
+    gold = golden("blocks")
+    mb = det_init_(OracleMetaBlock(48, 24))
+    V = det_tensor("mb.V", (5, 48)).requires_grad_(True)
+    U = det_tensor("mb.U", (5, 24)).requires_grad_(True)
+    y = mb(V, U); y.square().sum().backward()
+    assert torch.allclose(y.double(), torch.tensor(gold["metablock"]["y"], dtype=torch.float64), rtol=RTOL, atol=ATOL)
+    assert_summary_close(summarize(V.grad), gold["metablock"]["dV"], RTOL, ATOL)
+    assert_summary_close(summarize(U.grad), gold["metablock"]["dU"], RTOL, ATOL)
+
+    g = det_init_(OracleGatedResidual(64)); g.eval()
+    q = det_tensor("g.q", (1, 5, 64)).requires_grad_(True)
+    k = det_tensor("g.k", (1, 5, 64)).requires_grad_(True)
+    y = g(q, k, k); y.square().sum().backward()
+    assert torch.allclose(y.double(), torch.tensor(gold["gated_residual"]["y"], dtype=torch.float64), rtol=RTOL, atol=ATOL)
+    assert_summary_close(summarize(q.grad), gold["gated_residual"]["dq"], RTOL, ATOL)
+    assert_summary_close(summarize(k.grad), gold["gated_residual"]["dk"], RTOL, ATOL)
+
+    tt = det_init_(OracleTabTransformer([10] * 82, num_continuous=4, output_dim=85)); tt.eval()
+    xc = (det_tensor("tt.cat", (3, 82)).abs() * 10).long().clamp_(0, 9)
+    xn = det_tensor("tt.num", (3, 4))
+    y = tt(xc, xn)
+    assert torch.allclose(y.double(), torch.tensor(gold["tab_transformer"]["y"], dtype=torch.float64), rtol=1e-3, atol=1e-5)
