@@ -1,0 +1,144 @@
+/* mmskin.h -- C ABI of libmmskin_hip.so: the MI355X (gfx950) implementation of the
+ * MultimodalModel forward/backward hot path of life-ufes/multimodal-model-skin-lesion-classifier.
+ *
+ * The reference has no FFI / plugin boundary of its own: its boundary is the Python nn.Module
+ * contract of src/scripts/benchmark/models/multimodalIntraInterModal.py:13-416 (ctor :14-28,
+ * forward :162).  This header is the build-defined C replacement for the ATen operators that module
+ * invokes; each entry point names the reference call site whose arithmetic it replaces.  The Python
+ * shim in multimodal-model-skin-lesion-classifier_amd/models/ binds these with ctypes (see
+ * INTEGRATION.md).
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (no torch types, no allocation
+ * inside compute calls); `stream` is a hipStream_t passed as void*; all calls are asynchronous on that
+ * stream and return 0 on success, otherwise a MMSKIN_ERR_* code with mmskin_last_error() describing
+ * it.  Matrices are row-major.  dtype selects the backbone compute type: MMSKIN_F32 = exact fp32
+ * MFMA (parity mode), MMSKIN_BF16 = bf16 MFMA with fp32 accumulation (throughput mode).
+ */
+#ifndef MMSKIN_H
+#define MMSKIN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMSKIN_F32 0
+#define MMSKIN_BF16 1
+
+const char* mmskin_last_error(void);
+int mmskin_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image encoder plan (resnet-18 / resnet-50).  Replaces `self.image_encoder(image)`
+ * (multimodalIntraInterModal.py:167; factory loadImageModelClassifier.py:65-75) and its backward.
+ * Parameters: ONE flat fp32 buffer in torchvision named_parameters() order (conv.weight OIHW,
+ * bn.weight, bn.bias ...); buffers: ONE flat fp32 buffer (running_mean, running_var per BN).
+ * tensor_info enumerates names/offsets/shapes so the host can expose them as state_dict entries. */
+typedef struct mmskin_backbone* mmskin_backbone_t;
+int mmskin_backbone_create(const char* arch, int batch, int height, int width, int dtype, mmskin_backbone_t* out);
+void mmskin_backbone_destroy(mmskin_backbone_t h);
+int mmskin_backbone_num_tensors(mmskin_backbone_t h, int kind /*0 params, 1 buffers*/);
+int mmskin_backbone_tensor_info(mmskin_backbone_t h, int kind, int index, char* name, int name_cap,
+                                int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4);
+int64_t mmskin_backbone_param_numel(mmskin_backbone_t h);
+int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h);
+int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h);
+int mmskin_backbone_feature_dim(mmskin_backbone_t h);
+/* image_nchw: fp32 [batch,3,H,W]; features: fp32 [batch, feature_dim].  training!=0: batch-stat BN,
+ * running stats updated in `buffers`, activations kept in `workspace` for the backward call. */
+int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
+                            void* workspace, float* features, int training, void* stream);
+/* param_grads: flat fp32, same layout as params; every element is written. */
+int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,
+                             float* param_grads, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Op-level convolution / batch-norm entry points (same kernels the plan uses; NCHW fp32 at the
+ * boundary, converted to NHWC `dtype` inside `workspace`).  Used by the parity tests and by
+ * consumers that need a single layer.  conv weight OIHW fp32, no bias (torchvision ResNet convs). */
+int64_t mmskin_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad);
+int mmskin_conv2d_forward(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, int kh,
+                          int kw, int stride, int pad, int dtype, void* workspace, void* stream);
+/* dx (may be null) and dw (may be null) from dy [N,Cout,OH,OW] */
+int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, float* dx, float* dw, int N, int Cin,
+                           int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype, void* workspace,
+                           void* stream);
+/* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */
+int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W);
+int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float* y, float* save_mean, float* save_invstd, int N, int C, int H,
+                             int W, float eps, float momentum, int relu, int dtype, void* workspace, void* stream);
+int mmskin_batchnorm_backward(const float* dy, const float* x, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                              int N, int C, int H, int W, int relu, int dtype, void* workspace, void* stream);
+/* the ResNet stem: conv7x7/2 (OIHW [64,3,7,7]) -> BN(train) -> ReLU -> maxpool3x3/2; y [N,64,PH,PW] */
+int64_t mmskin_stem_workspace_bytes(int N, int H, int W);
+int mmskin_stem_forward(const float* x, const float* w, const float* gamma, const float* beta, float* y, int N, int H,
+                        int W, float eps, int dtype, void* workspace, void* stream);
+int mmskin_stem_backward(const float* dy, const float* x, const float* w, const float* gamma, const float* beta,
+                         float* dw, float* dgamma, float* dbeta, int N, int H, int W, float eps, int dtype,
+                         void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fusion-head operators (fp32).  Replace nn.Linear / nn.LayerNorm / nn.MultiheadAttention(L=1) /
+ * torch.sigmoid gates / MetaBlock / GatedAlteredResidualBlock pointwise math of
+ * multimodalIntraInterModal.py:172-412, metablock.py:27-32, gatedResidualBlock.py:12-17. */
+/* y[M,N] = x[M,K] @ w[N,K]^T + b (b may be null) ; relu!=0 applies max(.,0) */
+int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
+                          void* stream);
+/* dy[M,N]; if y_relu is given dy is first masked by (y_relu > 0).  Any of dx[M,K], dw[N,K], db[N] may be
+ * null.  dy_scratch[M,N] is required when y_relu is given (holds the masked dy). */
+int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
+                           float* dx, float* dw, float* db, int M, int K, int N, void* stream);
+/* y = LN(x)*g + b over the last dim, optional fused ReLU; mean/rstd [M] saved for backward */
+int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
+                             int M, int N, float eps, int relu, void* stream);
+int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, const float* b, const float* mean,
+                              const float* rstd, float* dx, float* dg, float* db, int M, int N, int relu, void* stream);
+/* out = sigmoid(z) * v                                  (multimodalIntraInterModal.py:219-235) */
+int mmskin_sigmoid_gate_forward(const float* z, const float* v, float* out, int64_t n, void* stream);
+int mmskin_sigmoid_gate_backward(const float* dout, const float* z, const float* v, float* dz, float* dv, int64_t n,
+                                 void* stream);
+/* out = g*a + (1-g)*q, g = sigmoid(z)                   (gatedResidualBlock.py:15-16) */
+int mmskin_gated_mix_forward(const float* z, const float* a, const float* q, float* out, int64_t n, void* stream);
+int mmskin_gated_mix_backward(const float* dout, const float* z, const float* a, const float* q, float* dz, float* da,
+                              float* dq, int64_t n, void* stream);
+/* out = sigmoid(tanh(V*t1) + t2)                        (metablock.py:31) */
+int mmskin_metablock_gate_forward(const float* V, const float* t1, const float* t2, float* out, int64_t n, void* stream);
+int mmskin_metablock_gate_backward(const float* dout, const float* V, const float* t1, const float* t2, float* dV,
+                                   float* dt1, float* dt2, int64_t n, void* stream);
+/* inverted dropout with a counter-based generator; mask[n] bytes (1 keep / 0 drop) */
+int mmskin_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                           uint64_t offset, void* stream);
+int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+/* out[M, Na+Nb] = [a | b]; backward splits */
+int mmskin_concat2_forward(const float* a, const float* b, float* out, int M, int Na, int Nb, void* stream);
+int mmskin_concat2_backward(const float* dout, float* da, float* db, int M, int Na, int Nb, void* stream);
+/* softmax attention for the metadata TabTransformer / generic L>1 attention:
+ * q,k,v [B,H,L,Dh] -> o [B,H,L,Dh], probs p [B,H,L,L] saved for backward */
+int mmskin_attention_forward(const float* q, const float* k, const float* v, float* o, float* p, int B, int H, int L,
+                             int Dh, void* stream);
+int mmskin_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* p,
+                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, void* stream);
+/* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
+int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
+                             void* stream);
+int mmskin_embedding_backward(const float* dout, const int64_t* ids, float* dtable, int B, int ncols, int card, int E,
+                              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * `custom-cnn` image encoder pieces (loadImageModelClassifier.py:50-60): small direct kernels for
+ * shapes the MFMA implicit GEMM does not cover (Cin=3, Cout=16).  NCHW fp32. */
+int mmskin_direct_conv2d_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+                                 int Cout, int kh, int kw, int stride, int pad, int relu, void* stream);
+int mmskin_direct_conv2d_backward(const float* dy, const float* x, const float* y_relu, float* dw, float* db, int N,
+                                  int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, void* stream);
+/* maxpool(k, stride=k) followed by global average pool: y[N,C]; idx for backward */
+int mmskin_pool_gap_forward(const float* x, float* y, int32_t* idx, int N, int C, int H, int W, int k, void* stream);
+int mmskin_pool_gap_backward(const float* dy, const int32_t* idx, float* dx, int N, int C, int H, int W, int k,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSKIN_H */

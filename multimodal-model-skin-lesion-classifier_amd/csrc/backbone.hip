@@ -1,0 +1,436 @@
+// ResNet image-encoder plan executor (resnet-18 / resnet-50, torchvision v1.5 layout).
+//
+// One C-ABI call runs the whole backbone forward (or backward) by launching the gfx950 kernels of
+// conv_gemm.hip / wgrad.hip / ops.hip back to back on the caller's stream: no Python per layer, no
+// allocation, graph-capturable.  Replaces `self.image_encoder(image)` of the reference
+// (multimodalIntraInterModal.py:167; factory loadImageModelClassifier.py:65-75) and its autograd
+// backward.  Parameters stay fp32 masters in one flat buffer laid out in torchvision's
+// named_parameters() order; they are re-staged to the compute dtype (K-contiguous GEMM operands) at
+// the start of every forward.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "conv.h"
+#include "ops.h"
+
+namespace {
+
+struct TensorInfo {
+  std::string name;
+  int64_t offset, numel;
+  int ndim;
+  int64_t shape[4];
+};
+
+struct Unit {  // conv + batch-norm
+  ConvShape s;
+  bool stem = false;
+  int64_t w_off, g_off, b_off;   // flat param offsets
+  int64_t rm_off, rv_off;        // flat buffer offsets
+  int64_t wf_off, wd_off;        // staged weight element offsets
+  size_t x_off;                  // raw conv output (bytes in workspace)
+  size_t y_off;                  // post-activation output (bytes); for the last unit of a block = block output
+  size_t coef_off;               // floats: scale, shift, mean, invstd (4*Cout)
+  size_t rows() const { return (size_t)s.N * s.OH() * s.OW(); }
+};
+
+struct Block {
+  std::vector<int> units;
+  int ds = -1;
+  size_t in_off;   // block input activation (bytes)
+  int in_C, in_H, in_W;
+};
+
+struct Plan {
+  int arch, N, H, W, dtype;
+  int feat_dim;
+  int Hp, Wp, OH0, OW0, PH, PW;
+  std::vector<TensorInfo> params, buffers;
+  int64_t param_numel = 0, buffer_numel = 0;
+  std::vector<Unit> units;
+  std::vector<Block> blocks;
+  StageDesc* table_dev = nullptr;
+  std::vector<StageDesc> table_host;
+  int max_stage_elems = 0;
+  int64_t staged_elems = 0;
+  // workspace layout (bytes)
+  size_t ws_bytes = 0;
+  size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[6], off_slab, off_partial,
+      off_coefbwd, off_dwv;
+  size_t maxact_bytes = 0, stat_bytes = 0;
+  size_t esz() const { return dtype == 1 ? 2 : 4; }
+};
+
+int64_t add_tensor(std::vector<TensorInfo>& v, int64_t& total, const std::string& name,
+                   std::initializer_list<int64_t> shape) {
+  TensorInfo t;
+  t.name = name;
+  t.offset = total;
+  t.ndim = (int)shape.size();
+  t.numel = 1;
+  int i = 0;
+  for (int64_t d : shape) { t.shape[i++] = d; t.numel *= d; }
+  for (; i < 4; ++i) t.shape[i] = 1;
+  total += t.numel;
+  v.push_back(t);
+  return t.offset;
+}
+
+int add_unit(Plan& p, const std::string& conv_name, const std::string& bn_name, ConvShape s) {
+  Unit u;
+  u.s = s;
+  u.w_off = add_tensor(p.params, p.param_numel, conv_name + ".weight", {s.Cout, s.Cin, s.kh, s.kw});
+  u.g_off = add_tensor(p.params, p.param_numel, bn_name + ".weight", {s.Cout});
+  u.b_off = add_tensor(p.params, p.param_numel, bn_name + ".bias", {s.Cout});
+  u.rm_off = add_tensor(p.buffers, p.buffer_numel, bn_name + ".running_mean", {s.Cout});
+  u.rv_off = add_tensor(p.buffers, p.buffer_numel, bn_name + ".running_var", {s.Cout});
+  p.units.push_back(u);
+  return (int)p.units.size() - 1;
+}
+
+size_t carve(size_t& cursor, size_t bytes) {
+  size_t o = cursor;
+  cursor = align_up(cursor + bytes, 256);
+  return o;
+}
+
+int build_plan(Plan& p) {
+  const bool bottleneck = p.arch == 50;
+  const int depths18[4] = {2, 2, 2, 2}, depths50[4] = {3, 4, 6, 3};
+  const int* depths = bottleneck ? depths50 : depths18;
+  const int expansion = bottleneck ? 4 : 1;
+  // stem
+  ConvShape s0 = {p.N, p.H, p.W, 3, 64, 7, 7, 2, 3};
+  int u0 = add_unit(p, "conv1", "bn1", s0);
+  p.units[u0].stem = true;
+  p.OH0 = s0.OH(); p.OW0 = s0.OW();
+  p.Hp = 2 * p.OH0 + 8; p.Wp = 2 * p.OW0 + 8;
+  if (p.Hp < p.H + 6) p.Hp = p.H + 6;
+  if (p.Wp < p.W + 6) p.Wp = p.W + 6;
+  p.Wp = (p.Wp + 1) / 2 * 2;
+  p.PH = (p.OH0 + 2 - 3) / 2 + 1; p.PW = (p.OW0 + 2 - 3) / 2 + 1;
+  int cin = 64, h = p.PH, w = p.PW;
+  const int widths[4] = {64, 128, 256, 512};
+  for (int li = 0; li < 4; ++li) {
+    for (int b = 0; b < depths[li]; ++b) {
+      const int stride = (b == 0 && li > 0) ? 2 : 1;
+      const int width = widths[li], cout = width * expansion;
+      std::string base = "layer" + std::to_string(li + 1) + "." + std::to_string(b);
+      Block blk;
+      blk.in_C = cin; blk.in_H = h; blk.in_W = w;
+      if (bottleneck) {
+        blk.units.push_back(add_unit(p, base + ".conv1", base + ".bn1", {p.N, h, w, cin, width, 1, 1, 1, 0}));
+        blk.units.push_back(add_unit(p, base + ".conv2", base + ".bn2", {p.N, h, w, width, width, 3, 3, stride, 1}));
+        int h2 = (h + 2 - 3) / stride + 1, w2 = (w + 2 - 3) / stride + 1;
+        blk.units.push_back(add_unit(p, base + ".conv3", base + ".bn3", {p.N, h2, w2, width, cout, 1, 1, 1, 0}));
+      } else {
+        blk.units.push_back(add_unit(p, base + ".conv1", base + ".bn1", {p.N, h, w, cin, width, 3, 3, stride, 1}));
+        int h2 = (h + 2 - 3) / stride + 1, w2 = (w + 2 - 3) / stride + 1;
+        blk.units.push_back(add_unit(p, base + ".conv2", base + ".bn2", {p.N, h2, w2, width, cout, 3, 3, 1, 1}));
+      }
+      if (stride != 1 || cin != cout)
+        blk.ds = add_unit(p, base + ".downsample.0", base + ".downsample.1", {p.N, h, w, cin, cout, 1, 1, stride, 0});
+      p.blocks.push_back(blk);
+      cin = cout;
+      h = (h + 2 - 3) / stride + 1;
+      w = (w + 2 - 3) / stride + 1;
+    }
+  }
+  p.feat_dim = cin;
+
+  // ---- staged weights + stage table
+  std::vector<StageDesc> table;
+  int64_t wf = 0, wd = 0;
+  for (Unit& u : p.units) {
+    StageDesc d = {};
+    d.src_off = u.w_off;
+    d.Cout = u.s.Cout; d.Cin = u.s.Cin; d.taps = u.s.kh * u.s.kw; d.stem = u.stem ? 1 : 0;
+    u.wf_off = wf; u.wd_off = wd;
+    d.fwd_off = wf; d.dgrad_off = wd;
+    int64_t n = u.stem ? 64 * 256 : (int64_t)d.Cout * d.Cin * d.taps;
+    wf += n;
+    if (!u.stem) wd += n;
+    if (d.Cout * d.Cin * d.taps > p.max_stage_elems) p.max_stage_elems = d.Cout * d.Cin * d.taps;
+    table.push_back(d);
+  }
+  p.staged_elems = wf;
+  p.table_host = table;  // uploaded by ensure_table() on the first forward (create() needs no GPU)
+
+  // ---- workspace layout
+  const size_t es = p.esz();
+  size_t cur = 0;
+  p.off_img4 = carve(cur, (size_t)p.N * p.Hp * p.Wp * 4 * es);
+  p.off_wf = carve(cur, (size_t)wf * es);
+  p.off_wd = carve(cur, (size_t)wd * es);
+  size_t stat_rows_max = 0, maxact = 0, slab_max = stem_wgrad_slab_bytes(p.N, p.OH0, p.OW0), partial_max = 0;
+  int maxC = 64;
+  for (Unit& u : p.units) {
+    size_t rows = u.rows();
+    size_t sr = (size_t)ceil_div((int)rows, 128) * u.s.Cout;
+    if (sr > stat_rows_max) stat_rows_max = sr;
+    if (rows * u.s.Cout > maxact) maxact = rows * u.s.Cout;
+    if ((size_t)u.s.N * u.s.H * u.s.W * u.s.Cin > maxact && !u.stem) maxact = (size_t)u.s.N * u.s.H * u.s.W * u.s.Cin;
+    if (!u.stem) { size_t sb = conv_wgrad_slab_bytes(u.s); if (sb > slab_max) slab_max = sb; }
+    size_t pr = (size_t)bn_bwd_partial_rows(rows, u.s.Cout) * 2 * u.s.Cout * sizeof(float);
+    if (pr > partial_max) partial_max = pr;
+    if (u.s.Cout > maxC) maxC = u.s.Cout;
+  }
+  p.stat_bytes = stat_rows_max * sizeof(float);
+  p.off_stat = carve(cur, 2 * p.stat_bytes);
+  p.maxact_bytes = maxact * es;
+  for (Unit& u : p.units) {
+    u.coef_off = carve(cur, 4 * (size_t)u.s.Cout * sizeof(float));
+    u.x_off = carve(cur, u.rows() * u.s.Cout * es);
+  }
+  p.off_pool = carve(cur, (size_t)p.N * p.PH * p.PW * 64 * es);
+  p.off_idx = carve(cur, (size_t)p.N * p.PH * p.PW * 64);
+  // post-activation outputs
+  size_t prev = p.off_pool;
+  for (Block& b : p.blocks) {
+    b.in_off = prev;
+    for (int ui : b.units) {
+      Unit& u = p.units[ui];
+      u.y_off = carve(cur, u.rows() * u.s.Cout * es);
+    }
+    prev = p.units[b.units.back()].y_off;
+  }
+  for (int i = 0; i < 6; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
+  p.off_slab = carve(cur, slab_max);
+  p.off_partial = carve(cur, partial_max);
+  p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
+  p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
+  p.ws_bytes = cur;
+  return MMSKIN_OK;
+}
+
+int ensure_table(Plan& p) {
+  if (p.table_dev) return MMSKIN_OK;
+  HIP_CHECK_RET(hipMalloc((void**)&p.table_dev, p.table_host.size() * sizeof(StageDesc)));
+  HIP_CHECK_RET(hipMemcpy(p.table_dev, p.table_host.data(), p.table_host.size() * sizeof(StageDesc),
+                          hipMemcpyHostToDevice));
+  return MMSKIN_OK;
+}
+
+template <typename T>
+int forward_impl(Plan& p, const float* image, const float* params, float* buffers, unsigned char* ws,
+                 float* features, bool training, hipStream_t st) {
+  const float eps = 1e-5f, mom = 0.1f;
+  T* wf = reinterpret_cast<T*>(ws + p.off_wf);
+  T* wd = reinterpret_cast<T*>(ws + p.off_wd);
+  float* stat_sum = reinterpret_cast<float*>(ws + p.off_stat);
+  float* stat_sq = reinterpret_cast<float*>(ws + p.off_stat + p.stat_bytes);
+  int rc;
+  if ((rc = ensure_table(p))) return rc;
+  // stage weights (stem region needs zeros in its padding taps)
+  HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
+  if ((rc = stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st))) return rc;
+
+  auto bn_coeffs = [&](Unit& u, int stat_rows) -> int {
+    float* coef = reinterpret_cast<float*>(ws + u.coef_off);
+    const int C = u.s.Cout;
+    if (training)
+      return bn_finalize(stat_sum, stat_sq, stat_rows, C, (double)u.rows(), params + u.g_off, params + u.b_off, eps,
+                         mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C, st);
+    return bn_eval_coeffs(C, params + u.g_off, params + u.b_off, buffers + u.rm_off, buffers + u.rv_off, eps, coef,
+                          coef + C, st);
+  };
+
+  // ---- stem
+  Unit& u0 = p.units[0];
+  T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
+  if ((rc = stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st))) return rc;
+  T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
+  if ((rc = launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
+                                    training ? stat_sum : nullptr, training ? stat_sq : nullptr, st))) return rc;
+  if ((rc = bn_coeffs(u0, stem_conv_stat_rows(p.N, p.OH0, p.OW0)))) return rc;
+  float* c0 = reinterpret_cast<float*>(ws + u0.coef_off);
+  T* pool = reinterpret_cast<T*>(ws + p.off_pool);
+  if ((rc = stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st))) return rc;
+
+  // ---- residual stages
+  for (Block& b : p.blocks) {
+    const T* in = reinterpret_cast<const T*>(ws + b.in_off);
+    const T* cur = in;
+    const int nu = (int)b.units.size();
+    if (b.ds >= 0) {
+      Unit& d = p.units[b.ds];
+      if ((rc = launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
+                                   training ? stat_sum : nullptr, training ? stat_sq : nullptr, st))) return rc;
+      if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
+    }
+    for (int i = 0; i < nu; ++i) {
+      Unit& u = p.units[b.units[i]];
+      T* x = reinterpret_cast<T*>(ws + u.x_off);
+      T* y = reinterpret_cast<T*>(ws + u.y_off);
+      if ((rc = launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
+                                   training ? stat_sq : nullptr, st))) return rc;
+      if ((rc = bn_coeffs(u, conv_fwd_stat_rows(u.s)))) return rc;
+      float* coef = reinterpret_cast<float*>(ws + u.coef_off);
+      const int C = u.s.Cout;
+      if (i + 1 < nu) {
+        if ((rc = bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st))) return rc;
+      } else if (b.ds >= 0) {
+        Unit& d = p.units[b.ds];
+        float* dc = reinterpret_cast<float*>(ws + d.coef_off);
+        if ((rc = bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(),
+                              C, true, st))) return rc;
+      } else {
+        if ((rc = bn_apply<T>(x, in, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st))) return rc;
+      }
+      cur = y;
+    }
+  }
+  Unit& last = p.units[p.blocks.back().units.back()];
+  return avgpool_fwd<T>(reinterpret_cast<const T*>(ws + last.y_off), p.N, last.s.OH() * last.s.OW(), last.s.Cout,
+                        features, st);
+}
+
+template <typename T>
+int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned char* ws, float* grads,
+                  hipStream_t st) {
+  T* wd = reinterpret_cast<T*>(ws + p.off_wd);
+  float* slab = reinterpret_cast<float*>(ws + p.off_slab);
+  float* partial = reinterpret_cast<float*>(ws + p.off_partial);
+  float* cA = reinterpret_cast<float*>(ws + p.off_coefbwd);
+  T* S[6];
+  for (int i = 0; i < 6; ++i) S[i] = reinterpret_cast<T*>(ws + p.off_scratch[i]);
+  int rc;
+
+  // BN backward of unit u given dy: fills dx (and optionally dz)
+  auto bn_backward = [&](Unit& u, const T* dy, const T* ymask, int mode, T* dx, T* dz) -> int {
+    const int C = u.s.Cout;
+    float* coef = reinterpret_cast<float*>(ws + u.coef_off);
+    const T* x = reinterpret_cast<const T*>(ws + u.x_off);
+    float* cB = cA + C; float* cC = cA + 2 * C;
+    int r;
+    if ((r = bn_bwd_reduce<T>(dy, x, ymask, coef, coef + C, mode, u.rows(), C, partial, st))) return r;
+    if ((r = bn_bwd_finalize(partial, bn_bwd_partial_rows(u.rows(), C), C, (double)u.rows(), params + u.g_off,
+                             coef + 2 * C, coef + 3 * C, grads + u.g_off, grads + u.b_off, cA, cB, cC, st))) return r;
+    return bn_bwd_apply<T>(dy, x, ymask, coef, coef + C, mode, cA, cB, cC, dx, dz, u.rows(), C, st);
+  };
+
+  Unit& last = p.units[p.blocks.back().units.back()];
+  T* g = S[0];
+  T* gin = S[1];
+  if ((rc = avgpool_bwd<T>(dfeat, p.N, last.s.OH() * last.s.OW(), last.s.Cout, g, st))) return rc;
+
+  for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
+    Block& b = p.blocks[bi];
+    const int nu = (int)b.units.size();
+    const T* in = reinterpret_cast<const T*>(ws + b.in_off);
+    Unit& ul = p.units[b.units[nu - 1]];
+    const T* out = reinterpret_cast<const T*>(ws + ul.y_off);
+    T* dX = S[2];
+    T* dY = S[3];
+    T* dZ = S[4];
+    T* dXd = S[5];
+    const bool has_ds = b.ds >= 0;
+    if ((rc = bn_backward(ul, g, out, MASK_FROM_Y, dX, has_ds ? nullptr : dZ))) return rc;
+    if (has_ds)
+      if ((rc = bn_backward(p.units[b.ds], g, out, MASK_FROM_Y, dXd, nullptr))) return rc;
+    for (int i = nu - 1; i >= 0; --i) {
+      Unit& u = p.units[b.units[i]];
+      const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
+      if ((rc = launch_conv_wgrad<T>(u.s, dX, uin, slab, grads + u.w_off, st))) return rc;
+      if (i > 0) {
+        Unit& up = p.units[b.units[i - 1]];
+        if ((rc = launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st))) return rc;
+        if ((rc = bn_backward(up, dY, nullptr, MASK_FROM_X, dX, nullptr))) return rc;
+      } else {
+        if ((rc = launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, has_ds ? (const T*)nullptr : dZ, st))) return rc;
+      }
+    }
+    if (has_ds) {
+      Unit& d = p.units[b.ds];
+      if ((rc = launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st))) return rc;
+      if ((rc = launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, gin, st))) return rc;
+    }
+    T* t = g; g = gin; gin = t;
+  }
+
+  // ---- stem: g = grad wrt pooled activation
+  Unit& u0 = p.units[0];
+  T* dyfull = S[2];
+  T* dx0 = S[3];
+  if ((rc = maxpool_bwd<T>(g, ws + p.off_idx, p.N, p.OH0, p.OW0, 64, dyfull, st))) return rc;
+  if ((rc = bn_backward(u0, dyfull, nullptr, MASK_FROM_X, dx0, nullptr))) return rc;
+  float* dwv = reinterpret_cast<float*>(ws + p.off_dwv);
+  if ((rc = launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),
+                                      slab, dwv, st))) return rc;
+  return stem_wgrad_unpack(dwv, grads + u0.w_off, st);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+#include "../../include/mmskin.h"
+
+struct mmskin_backbone { Plan plan; };
+
+extern "C" {
+
+int mmskin_backbone_create(const char* arch, int batch, int height, int width, int dtype, mmskin_backbone_t* out) {
+  ARG_CHECK(arch && out, "backbone_create: null argument");
+  int a = 0;
+  if (!strcmp(arch, "resnet-18")) a = 18;
+  else if (!strcmp(arch, "resnet-50")) a = 50;
+  else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
+  ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
+  ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
+  mmskin_backbone* h = new mmskin_backbone();
+  h->plan.arch = a; h->plan.N = batch; h->plan.H = height; h->plan.W = width; h->plan.dtype = dtype;
+  int rc = build_plan(h->plan);
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return MMSKIN_OK;
+}
+
+void mmskin_backbone_destroy(mmskin_backbone_t h) {
+  if (!h) return;
+  if (h->plan.table_dev) (void)hipFree(h->plan.table_dev);
+  delete h;
+}
+
+int mmskin_backbone_num_tensors(mmskin_backbone_t h, int kind) {
+  return (int)(kind == 0 ? h->plan.params.size() : h->plan.buffers.size());
+}
+
+int mmskin_backbone_tensor_info(mmskin_backbone_t h, int kind, int index, char* name, int name_cap,
+                                int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4) {
+  const std::vector<TensorInfo>& v = kind == 0 ? h->plan.params : h->plan.buffers;
+  ARG_CHECK(index >= 0 && index < (int)v.size(), "tensor_info: index %d out of range", index);
+  const TensorInfo& t = v[index];
+  if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  if (ndim) *ndim = t.ndim;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  return MMSKIN_OK;
+}
+
+int64_t mmskin_backbone_param_numel(mmskin_backbone_t h) { return h->plan.param_numel; }
+int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h) { return h->plan.buffer_numel; }
+int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h) { return (int64_t)h->plan.ws_bytes; }
+int mmskin_backbone_feature_dim(mmskin_backbone_t h) { return h->plan.feat_dim; }
+
+int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
+                            void* workspace, float* features, int training, void* stream) {
+  ARG_CHECK(h && image_nchw && params && buffers && workspace && features, "backbone_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->plan.dtype == MMSKIN_BF16)
+    return forward_impl<bf16_t>(h->plan, image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0, st);
+  return forward_impl<float>(h->plan, image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0, st);
+}
+
+int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,
+                             float* param_grads, void* stream) {
+  ARG_CHECK(h && dfeatures && params && workspace && param_grads, "backbone_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (h->plan.dtype == MMSKIN_BF16)
+    return backward_impl<bf16_t>(h->plan, dfeatures, params, (unsigned char*)workspace, param_grads, st);
+  return backward_impl<float>(h->plan, dfeatures, params, (unsigned char*)workspace, param_grads, st);
+}
+
+}  // extern "C"

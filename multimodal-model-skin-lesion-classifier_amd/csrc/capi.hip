@@ -1,0 +1,311 @@
+// C-ABI glue: error reporting + the op-level convolution / batch-norm / stem entry points.
+// These wrap exactly the kernels the backbone plan launches (conv_gemm.hip, wgrad.hip, ops.hip) with
+// NCHW fp32 tensors at the boundary, so every kernel can be parity-tested in isolation.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/mmskin.h"
+#include "conv.h"
+#include "ops.h"
+
+static thread_local char g_err[1024] = "";
+
+void mmskin_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+struct Carver {
+  unsigned char* base;
+  size_t cur = 0;
+  explicit Carver(void* p) : base((unsigned char*)p) {}
+  template <typename U> U* take(size_t count) {
+    size_t o = cur;
+    cur = align_up(cur + count * sizeof(U), 256);
+    return reinterpret_cast<U*>(base + o);
+  }
+};
+
+__global__ void coef_from_saved_kernel(int C, const float* gamma, const float* beta, const float* mean,
+                                       const float* invstd, float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float sc = gamma[c] * invstd[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - mean[c] * sc;
+  }
+}
+
+template <typename T>
+int stage_one(const float* w, int Cout, int Cin, int taps, bool stem, T* wfwd, T* wdgrad, StageDesc* table_dev,
+              hipStream_t st) {
+  StageDesc d = {};
+  d.src_off = 0; d.fwd_off = 0; d.dgrad_off = 0;
+  d.Cout = Cout; d.Cin = Cin; d.taps = taps; d.stem = stem ? 1 : 0;
+  HIP_CHECK_RET(hipMemcpyAsync(table_dev, &d, sizeof(d), hipMemcpyHostToDevice, st));
+  HIP_CHECK_RET(hipStreamSynchronize(st));  // `d` lives on this stack frame
+  if (stem) HIP_CHECK_RET(hipMemsetAsync(wfwd, 0, 64 * 256 * sizeof(T), st));
+  return stage_weights<T>(table_dev, 1, Cout * Cin * taps, w, wfwd, wdgrad, wdgrad != nullptr, st);
+}
+
+template <typename T>
+int conv_fwd_op(const float* x, const float* w, float* y, const ConvShape& s, void* ws, hipStream_t st) {
+  Carver c(ws);
+  StageDesc* table = c.take<StageDesc>(1);
+  T* xh = c.take<T>((size_t)s.N * s.H * s.W * s.Cin);
+  T* wf = c.take<T>((size_t)s.Cout * s.Cin * s.kh * s.kw);
+  T* yh = c.take<T>((size_t)s.N * s.OH() * s.OW() * s.Cout);
+  int rc;
+  if ((rc = nchw_to_nhwc<T>(x, s.N, s.Cin, s.H, s.W, xh, st))) return rc;
+  if ((rc = stage_one<T>(w, s.Cout, s.Cin, s.kh * s.kw, false, wf, (T*)nullptr, table, st))) return rc;
+  if ((rc = launch_conv_fwd<T>(s, xh, wf, yh, nullptr, nullptr, st))) return rc;
+  return nhwc_to_nchw<T>(yh, s.N, s.Cout, s.OH(), s.OW(), y, st);
+}
+
+template <typename T>
+int conv_bwd_op(const float* dy, const float* x, const float* w, float* dx, float* dw, const ConvShape& s, void* ws,
+                hipStream_t st) {
+  Carver c(ws);
+  StageDesc* table = c.take<StageDesc>(1);
+  T* xh = c.take<T>((size_t)s.N * s.H * s.W * s.Cin);
+  T* wf = c.take<T>((size_t)s.Cout * s.Cin * s.kh * s.kw);
+  T* yh = c.take<T>((size_t)s.N * s.OH() * s.OW() * s.Cout);  // dy in NHWC
+  T* wd = c.take<T>((size_t)s.Cout * s.Cin * s.kh * s.kw);
+  T* dxh = c.take<T>((size_t)s.N * s.H * s.W * s.Cin);
+  float* slab = c.take<float>(conv_wgrad_slab_bytes(s) / sizeof(float));
+  int rc;
+  if ((rc = nchw_to_nhwc<T>(dy, s.N, s.Cout, s.OH(), s.OW(), yh, st))) return rc;
+  if (dx) {
+    if ((rc = stage_one<T>(w, s.Cout, s.Cin, s.kh * s.kw, false, wf, wd, table, st))) return rc;
+    if ((rc = launch_conv_dgrad<T>(s, yh, wd, dxh, (const T*)nullptr, st))) return rc;
+    if ((rc = nhwc_to_nchw<T>(dxh, s.N, s.Cin, s.H, s.W, dx, st))) return rc;
+  }
+  if (dw) {
+    if ((rc = nchw_to_nhwc<T>(x, s.N, s.Cin, s.H, s.W, xh, st))) return rc;
+    if ((rc = launch_conv_wgrad<T>(s, yh, xh, slab, dw, st))) return rc;
+  }
+  return MMSKIN_OK;
+}
+
+template <typename T>
+int bn_fwd_op(const float* x, const float* gamma, const float* beta, float* rm, float* rv, float* y, float* save_mean,
+              float* save_invstd, int N, int C, int H, int W, float eps, float mom, int relu, void* ws, hipStream_t st) {
+  Carver c(ws);
+  const size_t rows = (size_t)N * H * W;
+  T* xh = c.take<T>(rows * C);
+  T* yh = c.take<T>(rows * C);
+  float* ssum = c.take<float>((size_t)column_stats_rows(rows, C) * C);
+  float* ssq = c.take<float>((size_t)column_stats_rows(rows, C) * C);
+  float* coef = c.take<float>(2 * (size_t)C);
+  int rc, nr = 0;
+  if ((rc = nchw_to_nhwc<T>(x, N, C, H, W, xh, st))) return rc;
+  if ((rc = column_stats<T>(xh, rows, C, ssum, ssq, &nr, st))) return rc;
+  if ((rc = bn_finalize(ssum, ssq, nr, C, (double)rows, gamma, beta, eps, mom, rm, rv, coef, coef + C, save_mean,
+                        save_invstd, st))) return rc;
+  if ((rc = bn_apply<T>(xh, nullptr, coef, coef + C, nullptr, nullptr, yh, rows, C, relu != 0, st))) return rc;
+  return nhwc_to_nchw<T>(yh, N, C, H, W, y, st);
+}
+
+template <typename T>
+int bn_bwd_op(const float* dy, const float* x, const float* gamma, const float* beta, const float* save_mean,
+              const float* save_invstd, float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W, int relu,
+              void* ws, hipStream_t st) {
+  Carver c(ws);
+  const size_t rows = (size_t)N * H * W;
+  T* xh = c.take<T>(rows * C);
+  T* dyh = c.take<T>(rows * C);
+  float* partial = c.take<float>((size_t)bn_bwd_partial_rows(rows, C) * 2 * C);
+  float* tail = c.take<float>((size_t)bn_bwd_partial_rows(rows, C) * C);  // keep layout equal to bn_fwd_op's
+  (void)tail;
+  float* coef = c.take<float>(5 * (size_t)C);
+  T* dxh = c.take<T>(rows * C);
+  int rc;
+  if ((rc = nchw_to_nhwc<T>(x, N, C, H, W, xh, st))) return rc;
+  if ((rc = nchw_to_nhwc<T>(dy, N, C, H, W, dyh, st))) return rc;
+  hipLaunchKernelGGL(coef_from_saved_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta, save_mean,
+                     save_invstd, coef, coef + C);
+  HIP_CHECK_RET(hipGetLastError());
+  const int mode = relu ? MASK_FROM_X : MASK_NONE;
+  if ((rc = bn_bwd_reduce<T>(dyh, xh, nullptr, coef, coef + C, mode, rows, C, partial, st))) return rc;
+  if ((rc = bn_bwd_finalize(partial, bn_bwd_partial_rows(rows, C), C, (double)rows, gamma, save_mean, save_invstd,
+                            dgamma, dbeta, coef + 2 * C, coef + 3 * C, coef + 4 * C, st))) return rc;
+  if ((rc = bn_bwd_apply<T>(dyh, xh, nullptr, coef, coef + C, mode, coef + 2 * C, coef + 3 * C, coef + 4 * C, dxh,
+                            (T*)nullptr, rows, C, st))) return rc;
+  return nhwc_to_nchw<T>(dxh, N, C, H, W, dx, st);
+}
+
+struct StemGeom {
+  int OH, OW, Hp, Wp, PH, PW;
+  StemGeom(int H, int W) {
+    OH = (H + 6 - 7) / 2 + 1; OW = (W + 6 - 7) / 2 + 1;
+    Hp = 2 * OH + 8; Wp = 2 * OW + 8;
+    if (Hp < H + 6) Hp = H + 6;
+    if (Wp < W + 6) Wp = W + 6;
+    Wp = (Wp + 1) / 2 * 2;
+    PH = (OH + 2 - 3) / 2 + 1; PW = (OW + 2 - 3) / 2 + 1;
+  }
+};
+
+template <typename T>
+struct StemWs {
+  StageDesc* table; T* img4; T* wv; T* x0; T* pool; uint8_t* idx; float* ssum; float* ssq; float* coef;
+  T* dpool; T* dyfull; T* dx0; float* partial; float* slab; float* dwv;
+  StemWs(void* ws, int N, int H, int W) {
+    StemGeom g(H, W);
+    Carver c(ws);
+    const size_t rows = (size_t)N * g.OH * g.OW;
+    table = c.take<StageDesc>(1);
+    img4 = c.take<T>((size_t)N * g.Hp * g.Wp * 4);
+    wv = c.take<T>(64 * 256);
+    x0 = c.take<T>(rows * 64);
+    pool = c.take<T>((size_t)N * g.PH * g.PW * 64);
+    idx = c.take<uint8_t>((size_t)N * g.PH * g.PW * 64);
+    ssum = c.take<float>((size_t)stem_conv_stat_rows(N, g.OH, g.OW) * 64);
+    ssq = c.take<float>((size_t)stem_conv_stat_rows(N, g.OH, g.OW) * 64);
+    coef = c.take<float>(7 * 64);
+    dpool = c.take<T>((size_t)N * g.PH * g.PW * 64);
+    dyfull = c.take<T>(rows * 64);
+    dx0 = c.take<T>(rows * 64);
+    partial = c.take<float>((size_t)bn_bwd_partial_rows(rows, 64) * 2 * 64);
+    slab = c.take<float>(stem_wgrad_slab_bytes(N, g.OH, g.OW) / sizeof(float));
+    dwv = c.take<float>(64 * 256);
+    total = c.cur;
+  }
+  size_t total;
+};
+
+template <typename T>
+int stem_fwd_core(StemWs<T>& s, const float* x, const float* w, const float* gamma, const float* beta, int N, int H,
+                  int W, float eps, hipStream_t st) {
+  StemGeom g(H, W);
+  int rc;
+  if ((rc = stem_pack<T>(x, N, H, W, g.Hp, g.Wp, s.img4, st))) return rc;
+  if ((rc = stage_one<T>(w, 64, 3, 49, true, s.wv, (T*)nullptr, s.table, st))) return rc;
+  if ((rc = launch_stem_conv_fwd<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.img4, s.wv, s.x0, s.ssum, s.ssq, st))) return rc;
+  if ((rc = bn_finalize(s.ssum, s.ssq, stem_conv_stat_rows(N, g.OH, g.OW), 64, (double)N * g.OH * g.OW, gamma, beta, eps,
+                        0.1f, nullptr, nullptr, s.coef, s.coef + 64, s.coef + 128, s.coef + 192, st))) return rc;
+  return stem_bn_relu_pool<T>(s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.pool, s.idx, st);
+}
+
+template <typename T>
+int stem_fwd_op(const float* x, const float* w, const float* gamma, const float* beta, float* y, int N, int H,
+                       int W, float eps, void* ws, hipStream_t st) {
+  StemWs<T> s(ws, N, H, W);
+  StemGeom g(H, W);
+  int rc;
+  if ((rc = stem_fwd_core<T>(s, x, w, gamma, beta, N, H, W, eps, st))) return rc;
+  return nhwc_to_nchw<T>(s.pool, N, 64, g.PH, g.PW, y, st);
+}
+
+template <typename T>
+int stem_bwd_op(const float* dy, const float* x, const float* w, const float* gamma, const float* beta,
+                       float* dw, float* dgamma, float* dbeta, int N, int H, int W, float eps, void* ws, hipStream_t st) {
+  StemWs<T> s(ws, N, H, W);
+  StemGeom g(H, W);
+  const size_t rows = (size_t)N * g.OH * g.OW;
+  int rc;
+  if ((rc = stem_fwd_core<T>(s, x, w, gamma, beta, N, H, W, eps, st))) return rc;
+  if ((rc = nchw_to_nhwc<T>(dy, N, 64, g.PH, g.PW, s.dpool, st))) return rc;
+  if ((rc = maxpool_bwd<T>(s.dpool, s.idx, N, g.OH, g.OW, 64, s.dyfull, st))) return rc;
+  if ((rc = bn_bwd_reduce<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, rows, 64, s.partial, st))) return rc;
+  if ((rc = bn_bwd_finalize(s.partial, bn_bwd_partial_rows(rows, 64), 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
+                            dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, st))) return rc;
+  if ((rc = bn_bwd_apply<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, s.coef + 256, s.coef + 320,
+                            s.coef + 384, s.dx0, (T*)nullptr, rows, 64, st))) return rc;
+  if ((rc = launch_stem_conv_wgrad<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.dx0, s.img4, s.slab, s.dwv, st))) return rc;
+  return stem_wgrad_unpack(s.dwv, dw, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mmskin_last_error(void) { return g_err; }
+int mmskin_version(void) { return 100; }
+
+int64_t mmskin_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad) {
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  size_t in = (size_t)N * H * W * Cin * 4, out = (size_t)N * s.OH() * s.OW() * Cout * 4;
+  size_t wgt = (size_t)Cout * Cin * kh * kw * 4;
+  size_t slab = (Cout % 64 == 0 && (Cin * kh * kw) % 64 == 0) ? conv_wgrad_slab_bytes(s) : 0;
+  return (int64_t)(2 * in + out + 2 * wgt + slab + 16 * 256);
+}
+
+#define DISPATCH(dtype, call_f32, call_bf16)                            \
+  do {                                                                  \
+    if ((dtype) == MMSKIN_F32) return call_f32;                         \
+    if ((dtype) == MMSKIN_BF16) return call_bf16;                       \
+    mmskin_set_error("unknown dtype %d", (dtype));                      \
+    return MMSKIN_ERR_ARG;                                              \
+  } while (0)
+
+int mmskin_conv2d_forward(const float* x, const float* w, float* y, int N, int Cin, int H, int W, int Cout, int kh,
+                          int kw, int stride, int pad, int dtype, void* workspace, void* stream) {
+  ARG_CHECK(x && w && y && workspace, "conv2d_forward: null argument");
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype, conv_fwd_op<float>(x, w, y, s, workspace, st), conv_fwd_op<bf16_t>(x, w, y, s, workspace, st));
+}
+
+int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, float* dx, float* dw, int N, int Cin,
+                           int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype, void* workspace,
+                           void* stream) {
+  ARG_CHECK(dy && x && w && workspace, "conv2d_backward: null argument");
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype, conv_bwd_op<float>(dy, x, w, dx, dw, s, workspace, st),
+           conv_bwd_op<bf16_t>(dy, x, w, dx, dw, s, workspace, st));
+}
+
+int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W) {
+  size_t rows = (size_t)N * H * W;
+  return (int64_t)(3 * rows * C * 4 + (size_t)bn_bwd_partial_rows(rows, C) * 3 * C * 4 + 8 * (size_t)C * 4 + 16 * 256);
+}
+
+int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float* y, float* save_mean, float* save_invstd, int N, int C, int H,
+                             int W, float eps, float momentum, int relu, int dtype, void* workspace, void* stream) {
+  ARG_CHECK(x && gamma && beta && y && save_mean && save_invstd && workspace, "batchnorm_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           bn_fwd_op<float>(x, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, N, C, H, W, eps, momentum, relu, workspace, st),
+           bn_fwd_op<bf16_t>(x, gamma, beta, running_mean, running_var, y, save_mean, save_invstd, N, C, H, W, eps, momentum, relu, workspace, st));
+}
+
+int mmskin_batchnorm_backward(const float* dy, const float* x, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, float* dx, float* dgamma, float* dbeta,
+                              int N, int C, int H, int W, int relu, int dtype, void* workspace, void* stream) {
+  ARG_CHECK(dy && x && gamma && beta && save_mean && save_invstd && dx && workspace, "batchnorm_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           bn_bwd_op<float>(dy, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, N, C, H, W, relu, workspace, st),
+           bn_bwd_op<bf16_t>(dy, x, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, N, C, H, W, relu, workspace, st));
+}
+
+int64_t mmskin_stem_workspace_bytes(int N, int H, int W) {
+  StemWs<float> s(nullptr, N, H, W);
+  return (int64_t)s.total + 4096;
+}
+
+int mmskin_stem_forward(const float* x, const float* w, const float* gamma, const float* beta, float* y, int N, int H,
+                        int W, float eps, int dtype, void* workspace, void* stream) {
+  ARG_CHECK(x && w && gamma && beta && y && workspace, "stem_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype, stem_fwd_op<float>(x, w, gamma, beta, y, N, H, W, eps, workspace, st),
+           stem_fwd_op<bf16_t>(x, w, gamma, beta, y, N, H, W, eps, workspace, st));
+}
+
+int mmskin_stem_backward(const float* dy, const float* x, const float* w, const float* gamma, const float* beta,
+                         float* dw, float* dgamma, float* dbeta, int N, int H, int W, float eps, int dtype,
+                         void* workspace, void* stream) {
+  ARG_CHECK(dy && x && w && gamma && beta && dw && workspace, "stem_backward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype, stem_bwd_op<float>(dy, x, w, gamma, beta, dw, dgamma, dbeta, N, H, W, eps, workspace, st),
+           stem_bwd_op<bf16_t>(dy, x, w, gamma, beta, dw, dgamma, dbeta, N, H, W, eps, workspace, st));
+}
+
+}  // extern "C"

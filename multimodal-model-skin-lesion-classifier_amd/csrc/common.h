@@ -1,0 +1,102 @@
+// Shared device/host helpers for the mmskin gfx950 kernels.
+// Activations inside the library are NHWC; T is float (exact f32 MFMA path, parity mode) or
+// bf16_t (bf16 MFMA with f32 accumulate, throughput mode).  16 bytes = one "chunk" = the unit
+// every loader moves per lane (8 bf16 or 4 f32); a K-tile row is always 128 bytes = 8 chunks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef uint16_t bf16_t;  // storage type for bf16 activations / staged weights
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define MMSKIN_OK 0
+#define MMSKIN_ERR_ARG 1
+#define MMSKIN_ERR_HIP 2
+#define MMSKIN_ERR_UNSUPPORTED 3
+
+void mmskin_set_error(const char* fmt, ...);
+
+#define HIP_CHECK_RET(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      mmskin_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return MMSKIN_ERR_HIP;                                                                 \
+    }                                                                                        \
+  } while (0)
+
+#define ARG_CHECK(cond, ...)          \
+  do {                                \
+    if (!(cond)) {                    \
+      mmskin_set_error(__VA_ARGS__);  \
+      return MMSKIN_ERR_ARG;          \
+    }                                 \
+  } while (0)
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int EPC = 4;   // elements per 16-byte chunk
+  static constexpr int BK = 32;   // elements per 128-byte K-tile row
+  static constexpr int ID = 0;
+};
+template <> struct DT<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int BK = 64;
+  static constexpr int ID = 1;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return bf16_bits_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)f32_to_bf16_bits(v); }
+
+// One 16-byte chunk viewed as EPC floats.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  float v[4];
+  __device__ __forceinline__ void load(const void* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(void* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Chunk<bf16_t> {
+  float v[8];
+  __device__ __forceinline__ void load(const void* p) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(void* p) const {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// XCD-aware tile order: blocks are dealt round-robin over the 8 XCDs, so give each XCD a
+// contiguous run of tile ids (bijective for any grid size).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

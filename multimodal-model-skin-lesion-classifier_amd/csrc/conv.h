@@ -1,0 +1,84 @@
+// Implicit-GEMM convolution on NHWC activations: host-side descriptors + launchers.
+#pragma once
+#include "common.h"
+
+// One conv layer (NHWC activations, square or rectangular kernel, symmetric padding).
+struct ConvShape {
+  int N, H, W, Cin, Cout, kh, kw, stride, pad;
+  int OH() const { return (H + 2 * pad - kh) / stride + 1; }
+  int OW() const { return (W + 2 * pad - kw) / stride + 1; }
+};
+
+#define MMSKIN_MAX_TAPS 12
+// A "tap class": a set of output pixels that all gather from the same list of taps.
+// Forward conv has one class (all kh*kw taps).  Strided dgrad has stride*stride classes, one per
+// output-pixel parity, each with only the taps that land on an integer source pixel.
+struct TapClass {
+  int a_dim, b_dim;    // class pixel grid (rows of this class = N * a_dim * b_dim)
+  int ph, pw;          // output pixel = (a*OS + ph, b*OS + pw)
+  int ntaps;
+  int mblk_start;      // first row-block index of this class in the launch
+  int rows;
+  int pad_;
+  int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS], wtap[MMSKIN_MAX_TAPS];
+};
+
+struct ConvGemmArgs {
+  const void* in;      // gather source  [N][IH][IW][Cpitch]
+  const void* w;       // staged weights [Cout][wtaps][C]   (K contiguous)
+  void* out;           // [N][OHf][OWf][Cout]
+  const void* addend;  // optional, same layout as out: out = acc + addend (may alias out)
+  float* stat_sum;     // optional per-row-block partial column sums   [total_mblk][Cout]
+  float* stat_sq;      // optional per-row-block partial column sum-sq [total_mblk][Cout]
+  int N, IH, IW, C, Cpitch;
+  int Cout, wrow;      // wrow = wtaps*C = elements per weight row
+  int Sy, Sx, OS;
+  int OHf, OWf;
+  int ncls, total_mblk, nblk_n;
+  TapClass cls[4];
+};
+
+// wgrad: dW[cout][tap][c] = sum_m dY[m][cout] * gather(in)[m][tap][c]
+struct WgradArgs {
+  const void* dy;      // [M][Cout]   (M = N*OH*OW, NHWC flattened)
+  const void* in;      // gather source [N][IH][IW][Cpitch]
+  float* slab;         // [nsplit][Cout][Ktot] fp32 partials
+  int N, IH, IW, C, Cpitch;
+  int OH, OW;          // rows m = (img, oy, ox)
+  int Cout, Ktot;      // Ktot = ntaps*C
+  int Sy, Sx;
+  int ntaps;
+  int M, m_per_split, nsplit;
+  int nblk_o, nblk_k;  // tiles over Cout / Ktot
+  int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
+};
+
+template <typename T>
+int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
+                    float* stat_sq, hipStream_t st);
+// number of stat partial rows the forward launch produces (rows of stat_sum / stat_sq)
+int conv_fwd_stat_rows(const ConvShape& s);
+
+// din[N][H][W][Cin] = dgrad(dout[N][OH][OW][Cout]); wt_staged is [Cin][kh*kw][Cout].
+// addend (optional, may alias din) is added in the epilogue.  accumulate_only_touched: for classes
+// with no taps (e.g. 1x1 stride 2) leave din untouched when addend aliases din, else write zeros.
+template <typename T>
+int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* din, const T* addend,
+                      hipStream_t st);
+
+// The stem conv (7x7 s2 p3, Cin=3) runs as a "virtual" 8x1-tap conv with 32 channels over the padded
+// NHWC4 image produced by stem_pack (see stem.hip).  out = [N][OH][OW][64].
+template <typename T>
+int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, const T* wv, T* out,
+                         float* stat_sum, float* stat_sq, hipStream_t st);
+int stem_conv_stat_rows(int N, int OH, int OW);
+
+size_t conv_wgrad_slab_bytes(const ConvShape& s);
+// dw_kc: fp32 [Cout][kh*kw][Cin] (tap-major, channel-minor), reduced over the split slabs.
+template <typename T>
+int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw_kc,
+                      hipStream_t st);
+size_t stem_wgrad_slab_bytes(int N, int OH, int OW);
+template <typename T>
+int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout, const T* img4,
+                           float* slab, float* dwv, hipStream_t st);

@@ -1,0 +1,376 @@
+// Tapped gather-GEMM for gfx950: forward convolution and data-gradient (dgrad) as one kernel.
+//
+//   out[pix][n] = sum_{tap,c} in[pix + tap][c] * w[n][tap][c]        (+ addend[pix][n])
+//
+// Replaces the ATen/cuDNN conv2d forward + conv_backward(input) that the reference reaches through
+// torchvision's ResNet (multimodalIntraInterModal.py:167 -> loadImageModelClassifier.py:65-75).
+//
+// Design (MI355X): 256-thread workgroup (4 waves, one per SIMD), BM x BN output tile, K-tiles of
+// 128 bytes per row (64 bf16 / 32 f32).  Both operands are K-contiguous, so a lane's 16-byte chunk
+// is directly an MFMA operand fragment (v_mfma_f32_16x16x32_bf16, or 4x v_mfma_f32_16x16x4_f32 in
+// the exact-f32 parity mode).  Register-staged double buffering: global loads of tile k+1 are in
+// flight while tile k is read from LDS and multiplied; one barrier per K-tile.  LDS rows are
+// XOR-swizzled (chunk ^= (row>>1)&7) so ds_read_b128 fragment reads are bank-conflict free.
+// Weights are the MFMA "A" operand and pixels the "B" operand, so each lane ends up holding four
+// consecutive output channels of one pixel -> packed LDS-staged epilogue with full-line stores.
+// Optional epilogue: per-row-block BatchNorm partial sums (deterministic slab, no atomics), and an
+// addend tensor (residual / accumulation).
+#include "conv.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+#define TAP_LDS_BYTES 256
+
+template <int BM, int BN, typename T> constexpr int conv_gemm_lds_bytes() {
+  constexpr int ab = 2 * (BM + BN) * 128;
+  constexpr int cpitch = BN * (int)sizeof(T) + 16;
+  constexpr int rows_per_pass = 256 / (BN / DT<T>::EPC);
+  constexpr int cs = BM * cpitch + 2 * rows_per_pass * BN * 4;
+  return TAP_LDS_BYTES + (ab > cs ? ab : cs);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p) {
+  constexpr int EPC = DT<T>::EPC, BK = DT<T>::BK;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
+  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int CPITCH = BN * (int)sizeof(T) + 16;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* s_tap = reinterpret_cast<int*>(smem);
+  unsigned char* As = smem + TAP_LDS_BYTES;
+  unsigned char* Bs = As + 2 * A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = tile / p.nblk_n, nblk = tile - mblk * p.nblk_n;
+  int ci = 0;
+  for (int i = 1; i < p.ncls; ++i)
+    if (mblk >= p.cls[i].mblk_start) ci = i;
+  const int a_dim = p.cls[ci].a_dim, b_dim = p.cls[ci].b_dim;
+  const int ntaps = p.cls[ci].ntaps, rows = p.cls[ci].rows;
+  const int m0 = (mblk - p.cls[ci].mblk_start) * BM;
+  const int n0 = nblk * BN;
+  const int C = p.C, IH = p.IH, IW = p.IW;
+
+  if (tid < ntaps) {
+    int oy = p.cls[ci].offy[tid], ox = p.cls[ci].offx[tid], wt = p.cls[ci].wtap[tid];
+    s_tap[tid] = (oy * IW + ox) * p.Cpitch;
+    s_tap[16 + tid] = (oy & 0xffff) | (ox << 16);
+    s_tap[32 + tid] = wt * C;
+  }
+  __syncthreads();
+
+  // ---- loader state: this thread moves chunk column jc of rows lr + 32*i
+  const int lr = tid >> 3, jc = tid & 7;
+  int a_base[AP], a_iy[AP], a_ix[AP];
+  const int ab = a_dim * b_dim;
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    int m = m0 + lr + 32 * i;
+    if (m < rows) {
+      int img = m / ab, rem = m - img * ab;
+      int a = rem / b_dim, b = rem - a * b_dim;
+      a_iy[i] = a * p.Sy;
+      a_ix[i] = b * p.Sx;
+      a_base[i] = ((img * IH + a_iy[i]) * IW + a_ix[i]) * p.Cpitch;
+    } else {
+      a_iy[i] = -(1 << 20);
+      a_ix[i] = -(1 << 20);
+      a_base[i] = 0;
+    }
+  }
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w) +
+                             (size_t)(n0 + lr) * p.wrow * sizeof(T);
+  const size_t w_pass = (size_t)32 * p.wrow * sizeof(T);
+
+  int tap = 0, c = jc * EPC;
+  while (c >= C) { c -= C; ++tap; }
+  const int nk = ntaps * C / BK;
+
+  uint4 ra[AP], rb[BP];
+  auto load_tile = [&]() {
+    const int toff = s_tap[tap], tyx = s_tap[16 + tap], wk = s_tap[32 + tap] + c;
+    const int oy = (int)(short)(tyx & 0xffff), ox = tyx >> 16;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
+      bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+      rb[i] = *reinterpret_cast<const uint4*>(w_b + i * w_pass + (size_t)wk * sizeof(T));
+    c += BK;
+    while (c >= C) { c -= C; ++tap; }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int row = lr + 32 * i;
+      *reinterpret_cast<uint4*>(As + buf * A_BYTES + row * 128 + ((jc ^ ((row >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      int row = lr + 32 * i;
+      *reinterpret_cast<uint4*>(Bs + buf * B_BYTES + row * 128 + ((jc ^ ((row >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wm = wid / WAVES_N, wn = wid - wm * WAVES_N;
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile();
+    const unsigned char* Ab = As + cur * A_BYTES + (wm * WM + l15) * 128;
+    const unsigned char* Bb = Bs + cur * B_BYTES + (wn * WN + l15) * 128;
+    const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int off = ((4 * s + g) ^ sw) << 4;
+      uint4 fa[FM], fb[FN];
+#pragma unroll
+      for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(Ab + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(Bb + i * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc -> LDS [pixel][channel] (packed) -> coalesced 16-byte stores
+  unsigned char* Cs = smem + TAP_LDS_BYTES;
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+      int prow = wm * WM + j * 16 + l15;
+      int ccol = wn * WN + i * 16 + g * 4;
+      unsigned char* dst = Cs + prow * CPITCH + ccol * (int)sizeof(T);
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      } else {
+        uint32_t lo = f32_to_bf16_bits(acc[i][j][0]) | (f32_to_bf16_bits(acc[i][j][1]) << 16);
+        uint32_t hi = f32_to_bf16_bits(acc[i][j][2]) | (f32_to_bf16_bits(acc[i][j][3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+      }
+    }
+  __syncthreads();
+
+  constexpr int CH_PER_ROW = BN / EPC;
+  constexpr int ROWS_PER_PASS = 256 / CH_PER_ROW;
+  const int cj = tid % CH_PER_ROW, r0 = tid / CH_PER_ROW;
+  float ssum[EPC], ssq[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  const unsigned char* add_b = reinterpret_cast<const unsigned char*>(p.addend);
+  const bool simple_rows = (p.OS == 1 && p.ncls == 1);
+  const int ph = p.cls[ci].ph, pw = p.cls[ci].pw;
+  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
+    int m = m0 + row;
+    if (m >= rows) break;
+    int orow = m;
+    if (!simple_rows) {
+      int img = m / ab, rem = m - img * ab;
+      int a = rem / b_dim, b = rem - a * b_dim;
+      orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
+    }
+    Chunk<T> v;
+    v.load(Cs + row * CPITCH + cj * 16);
+    size_t goff = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
+    if (add_b) {
+      Chunk<T> ad;
+      ad.load(add_b + goff);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] += ad.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
+    v.store(out_b + goff);
+  }
+  if (p.stat_sum) {
+    float* red = reinterpret_cast<float*>(Cs + BM * CPITCH);  // [2][ROWS_PER_PASS][BN]
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[r0 * BN + cj * EPC + e] = ssum[e];
+      red[(ROWS_PER_PASS + r0) * BN + cj * EPC + e] = ssq[e];
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < ROWS_PER_PASS; ++r) { s += red[r * BN + tid]; q += red[(ROWS_PER_PASS + r) * BN + tid]; }
+      p.stat_sum[(size_t)mblk * p.Cout + n0 + tid] = s;
+      p.stat_sq[(size_t)mblk * p.Cout + n0 + tid] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <typename T, int BM, int BN, int WMv, int WNv>
+static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+  constexpr int lds = conv_gemm_lds_bytes<BM, BN, T>();
+  static bool attr_done = false;
+  auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv>;
+  if (!attr_done) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  int grid = a.total_mblk * a.nblk_n;
+  if (grid == 0) return MMSKIN_OK;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+#define CONV_BM 128
+
+template <typename T>
+static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
+  ARG_CHECK(a.Cout % 64 == 0, "conv_gemm: Cout=%d must be a multiple of 64", a.Cout);
+  ARG_CHECK((a.C % DT<T>::EPC) == 0, "conv_gemm: C=%d not a multiple of %d", a.C, DT<T>::EPC);
+  for (int i = 0; i < a.ncls; ++i)
+    ARG_CHECK((a.cls[i].ntaps * a.C) % DT<T>::BK == 0, "conv_gemm: K=%d not a multiple of %d",
+              a.cls[i].ntaps * a.C, DT<T>::BK);
+  if (a.Cout % 128 == 0) {
+    a.nblk_n = a.Cout / 128;
+    return launch_cfg<T, CONV_BM, 128, 2, 2>(a, st);
+  }
+  a.nblk_n = a.Cout / 64;
+  return launch_cfg<T, CONV_BM, 64, 2, 2>(a, st);
+}
+
+static void finish_classes(ConvGemmArgs& a) {
+  int blk = 0;
+  for (int i = 0; i < a.ncls; ++i) {
+    a.cls[i].rows = a.N * a.cls[i].a_dim * a.cls[i].b_dim;
+    a.cls[i].mblk_start = blk;
+    blk += ceil_div(a.cls[i].rows, CONV_BM);
+  }
+  a.total_mblk = blk;
+}
+
+int conv_fwd_stat_rows(const ConvShape& s) { return ceil_div(s.N * s.OH() * s.OW(), CONV_BM); }
+int stem_conv_stat_rows(int N, int OH, int OW) { return ceil_div(N * OH * OW, CONV_BM); }
+
+template <typename T>
+int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
+                    float* stat_sq, hipStream_t st) {
+  ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
+  ConvGemmArgs a = {};
+  a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
+  a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;
+  a.Sy = s.stride; a.Sx = s.stride; a.OS = 1;
+  a.OHf = s.OH(); a.OWf = s.OW();
+  a.ncls = 1;
+  TapClass& c = a.cls[0];
+  c.a_dim = s.OH(); c.b_dim = s.OW(); c.ph = 0; c.pw = 0; c.ntaps = s.kh * s.kw;
+  for (int r = 0; r < s.kh; ++r)
+    for (int q = 0; q < s.kw; ++q) {
+      int t = r * s.kw + q;
+      c.offy[t] = (int8_t)(r - s.pad); c.offx[t] = (int8_t)(q - s.pad); c.wtap[t] = (int8_t)t;
+    }
+  finish_classes(a);
+  return dispatch_conv_gemm<T>(a, st);
+}
+
+template <typename T>
+int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* din, const T* addend,
+                      hipStream_t st) {
+  ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_dgrad: too many taps");
+  ARG_CHECK(s.stride == 1 || s.stride == 2, "conv_dgrad: stride %d unsupported", s.stride);
+  ConvGemmArgs a = {};
+  a.in = dout; a.w = wt_staged; a.out = din; a.addend = addend;
+  a.N = s.N; a.IH = s.OH(); a.IW = s.OW(); a.C = s.Cout; a.Cpitch = s.Cout;
+  a.Cout = s.Cin; a.wrow = s.kh * s.kw * s.Cout;
+  a.Sy = 1; a.Sx = 1; a.OS = s.stride;
+  a.OHf = s.H; a.OWf = s.W;
+  a.ncls = 0;
+  for (int ph = 0; ph < s.stride; ++ph)
+    for (int pw = 0; pw < s.stride; ++pw) {
+      TapClass c = {};
+      c.a_dim = (s.H - ph + s.stride - 1) / s.stride;
+      c.b_dim = (s.W - pw + s.stride - 1) / s.stride;
+      c.ph = ph; c.pw = pw; c.ntaps = 0;
+      for (int r = 0; r < s.kh; ++r) {
+        if ((ph + s.pad - r) % s.stride != 0) continue;
+        for (int q = 0; q < s.kw; ++q) {
+          if ((pw + s.pad - q) % s.stride != 0) continue;
+          int t = c.ntaps++;
+          c.offy[t] = (int8_t)((ph + s.pad - r) / s.stride);
+          c.offx[t] = (int8_t)((pw + s.pad - q) / s.stride);
+          c.wtap[t] = (int8_t)(r * s.kw + q);
+        }
+      }
+      if (c.a_dim <= 0 || c.b_dim <= 0) continue;
+      // a tap-less class contributes zeros: skip it when accumulating in place
+      if (c.ntaps == 0 && addend == din && addend != nullptr) continue;
+      a.cls[a.ncls++] = c;
+    }
+  finish_classes(a);
+  return dispatch_conv_gemm<T>(a, st);
+}
+
+template <typename T>
+int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, const T* wv, T* out,
+                         float* stat_sum, float* stat_sq, hipStream_t st) {
+  // virtual conv: macro pixel = 2 real pixels x 4 channels = 8 elements; one tap per kernel row r,
+  // each reading 32 contiguous elements (8 real pixels x 4 ch) starting at macro pixel wo.
+  ConvGemmArgs a = {};
+  a.in = img4; a.w = wv; a.out = out; a.addend = nullptr;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.N = N; a.IH = Hp; a.IW = Wp / 2; a.C = 32; a.Cpitch = 8;
+  a.Cout = 64; a.wrow = 8 * 32;
+  a.Sy = 2; a.Sx = 1; a.OS = 1;
+  a.OHf = OH; a.OWf = OW;
+  a.ncls = 1;
+  TapClass& c = a.cls[0];
+  c.a_dim = OH; c.b_dim = OW; c.ph = 0; c.pw = 0; c.ntaps = 8;
+  for (int r = 0; r < 8; ++r) { c.offy[r] = (int8_t)r; c.offx[r] = 0; c.wtap[r] = (int8_t)r; }
+  finish_classes(a);
+  ARG_CHECK(2 * (OH - 1) + 7 < Hp && (OW - 1) + 3 < Wp / 2, "stem conv: padded image too small");
+  return dispatch_conv_gemm<T>(a, st);
+}
+
+#define INST(T)                                                                                      \
+  template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t); \
+  template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t);      \
+  template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);
+INST(float)
+INST(bf16_t)

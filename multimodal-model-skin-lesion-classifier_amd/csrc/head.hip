@@ -1,0 +1,622 @@
+// Fusion-head operators (fp32) for gfx950.  Replaces nn.Linear / nn.LayerNorm / sigmoid gates /
+// MetaBlock / gated-residual pointwise math / small softmax attention / embedding gather of
+// multimodalIntraInterModal.py:172-412, metablock.py:27-32, gatedResidualBlock.py:12-17,
+// tab_transformer.py:40-60.  Dense contractions run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32);
+// row reductions (LayerNorm, softmax) are wavefront-shuffle reductions, one 64-lane wave per row.
+#include "../../include/mmskin.h"
+#include "common.h"
+
+#define ST(s) ((hipStream_t)(s))
+
+// ------------------------------------------------------------------ generic strided f32 GEMM
+// C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]) ; A(m,k) = a[m*sam + k*sak] ; B(n,k) = b[n*sbn + k*sbk]
+#define LG_PITCH 80
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ c, const float* __restrict__ bias, int M,
+                                                       int N, int K, int64_t sam, int64_t sak, int64_t sbn,
+                                                       int64_t sbk, int64_t ldc, int relu) {
+  __shared__ float As[16 * LG_PITCH];
+  __shared__ float Bs[16 * LG_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int wm = wid >> 1, wn = wid & 1;
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int e = tid + 256 * i;
+      int row, kk;
+      if (A_KC) { row = e >> 4; kk = e & 15; } else { row = e & 63; kk = e >> 6; }
+      float v = 0.f;
+      if (m0 + row < M && k0 + kk < K) v = a[(int64_t)(m0 + row) * sam + (int64_t)(k0 + kk) * sak];
+      As[kk * LG_PITCH + row] = v;
+      if (B_KC) { row = e >> 4; kk = e & 15; } else { row = e & 63; kk = e >> 6; }
+      v = 0.f;
+      if (n0 + row < N && k0 + kk < K) v = b[(int64_t)(n0 + row) * sbn + (int64_t)(k0 + kk) * sbk];
+      Bs[kk * LG_PITCH + row] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fa[j] = As[(4 * s + g) * LG_PITCH + wm * 32 + j * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fb[i] = Bs[(4 * s + g) * LG_PITCH + wn * 32 + i * 16 + l15];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = n][j = m]: lane holds m = l15, n = 4g + reg
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = m0 + wm * 32 + j * 16 + l15;
+      if (m >= M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = n0 + wn * 32 + i * 16 + 4 * g + r;
+        if (n < N) {
+          float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
+          if (relu) v = fmaxf(v, 0.f);
+          c[(int64_t)m * ldc + n] = v;
+        }
+      }
+    }
+}
+
+static int gemm_f32(const float* a, const float* b, float* c, const float* bias, int M, int N, int K, int64_t sam,
+                    int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int relu, hipStream_t st) {
+  if (M <= 0 || N <= 0) return MMSKIN_OK;
+  dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+  const bool akc = sak == 1, bkc = sbk == 1;
+#define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, c, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu)
+  if (akc && bkc) LAUNCH(true, true);
+  else if (akc) LAUNCH(true, false);
+  else if (bkc) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+__global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += x[(int64_t)m * N + n];
+    out[n] = s;
+  }
+}
+static inline int grid1d(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ LayerNorm
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                            int N, float eps, int relu) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * N;
+  float s = 0.f;
+  for (int i = lane; i < N; i += 64) s += xr[i];
+  const float mu = wave_sum(s) / (float)N;
+  float q = 0.f;
+  for (int i = lane; i < N; i += 64) { float d = xr[i] - mu; q += d * d; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+  for (int i = lane; i < N; i += 64) {
+    float v = (xr[i] - mu) * rs * g[i] + b[i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[(int64_t)row * N + i] = v;
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ g, const float* __restrict__ b,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ dx,
+                                                               int M, int N, int relu) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float mu = mean[row], rs = rstd[row];
+  const float* xr = x + (int64_t)row * N;
+  const float* dr = dy + (int64_t)row * N;
+  float c1 = 0.f, c2 = 0.f;
+  for (int i = lane; i < N; i += 64) {
+    float xh = (xr[i] - mu) * rs;
+    float d = dr[i];
+    if (relu && !(xh * g[i] + b[i] > 0.f)) d = 0.f;
+    float dg = d * g[i];
+    c1 += dg; c2 += dg * xh;
+  }
+  c1 = wave_sum(c1) / (float)N; c2 = wave_sum(c2) / (float)N;
+  for (int i = lane; i < N; i += 64) {
+    float xh = (xr[i] - mu) * rs;
+    float d = dr[i];
+    if (relu && !(xh * g[i] + b[i] > 0.f)) d = 0.f;
+    dx[(int64_t)row * N + i] = rs * (d * g[i] - c1 - xh * c2);
+  }
+}
+__global__ void layernorm_bwd_gb_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                        const float* __restrict__ g, const float* __restrict__ b,
+                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                        float* __restrict__ dg, float* __restrict__ db, int M, int N, int relu) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float sg = 0.f, sb = 0.f;
+  const float gn = g[n], bn = b[n];
+  for (int m = 0; m < M; ++m) {
+    float xh = (x[(int64_t)m * N + n] - mean[m]) * rstd[m];
+    float d = dy[(int64_t)m * N + n];
+    if (relu && !(xh * gn + bn > 0.f)) d = 0.f;
+    sg += d * xh; sb += d;
+  }
+  if (dg) dg[n] = sg;
+  if (db) db[n] = sb;
+}
+
+// ------------------------------------------------------------------ pointwise gates
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+
+#define EW_LOOP(n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void sigmoid_gate_fwd_kernel(const float* z, const float* v, float* out, int64_t n) {
+  EW_LOOP(n) out[i] = (1.f / (1.f + expf(-z[i]))) * v[i];
+}
+__global__ void sigmoid_gate_bwd_kernel(const float* dout, const float* z, const float* v, float* dz, float* dv, int64_t n) {
+  EW_LOOP(n) {
+    float s = 1.f / (1.f + expf(-z[i]));
+    float d = dout[i];
+    dz[i] = d * v[i] * s * (1.f - s);
+    dv[i] = d * s;
+  }
+}
+__global__ void gated_mix_fwd_kernel(const float* z, const float* a, const float* q, float* out, int64_t n) {
+  EW_LOOP(n) {
+    float gt = 1.f / (1.f + expf(-z[i]));
+    out[i] = gt * a[i] + (1.f - gt) * q[i];
+  }
+}
+__global__ void gated_mix_bwd_kernel(const float* dout, const float* z, const float* a, const float* q, float* dz,
+                                     float* da, float* dq, int64_t n) {
+  EW_LOOP(n) {
+    float gt = 1.f / (1.f + expf(-z[i]));
+    float d = dout[i];
+    dz[i] = d * (a[i] - q[i]) * gt * (1.f - gt);
+    da[i] = d * gt;
+    dq[i] = d * (1.f - gt);
+  }
+}
+__global__ void metablock_gate_fwd_kernel(const float* V, const float* t1, const float* t2, float* out, int64_t n) {
+  EW_LOOP(n) out[i] = 1.f / (1.f + expf(-(tanhf(V[i] * t1[i]) + t2[i])));
+}
+__global__ void metablock_gate_bwd_kernel(const float* dout, const float* V, const float* t1, const float* t2,
+                                          float* dV, float* dt1, float* dt2, int64_t n) {
+  EW_LOOP(n) {
+    float u = tanhf(V[i] * t1[i]);
+    float o = 1.f / (1.f + expf(-(u + t2[i])));
+    float ds = dout[i] * o * (1.f - o);
+    float dp = ds * (1.f - u * u);
+    dt2[i] = ds;
+    dV[i] = dp * t1[i];
+    dt1[i] = dp * V[i];
+  }
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
+                                   uint64_t offset) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  EW_LOOP(n) {
+    uint64_t h = mix64(mix64(seed) ^ (offset + (uint64_t)i));
+    float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    uint8_t keep = u >= p ? 1 : 0;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
+__global__ void dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  EW_LOOP(n) dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+__global__ void concat2_fwd_kernel(const float* a, const float* b, float* out, int M, int Na, int Nb) {
+  const int N = Na + Nb;
+  EW_LOOP((int64_t)M * N) {
+    int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    out[i] = n < Na ? a[(int64_t)m * Na + n] : b[(int64_t)m * Nb + n - Na];
+  }
+}
+__global__ void concat2_bwd_kernel(const float* dout, float* da, float* db, int M, int Na, int Nb) {
+  const int N = Na + Nb;
+  EW_LOOP((int64_t)M * N) {
+    int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+    if (n < Na) da[(int64_t)m * Na + n] = dout[i];
+    else db[(int64_t)m * Nb + n - Na] = dout[i];
+  }
+}
+
+// ------------------------------------------------------------------ small softmax attention
+// one workgroup per (b, h); L*L scores in LDS; one wave per score row for the softmax.
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, float* __restrict__ o,
+                                                            float* __restrict__ p, int L, int Dh) {
+  extern __shared__ float sc[];  // [L][L]
+  const int64_t base = (int64_t)blockIdx.x * L * Dh;
+  const float scale = 1.0f / sqrtf((float)Dh);
+  for (int idx = threadIdx.x; idx < L * L; idx += 256) {
+    int i = idx / L, j = idx - i * L;
+    float s = 0.f;
+    for (int d = 0; d < Dh; ++d) s += q[base + i * Dh + d] * k[base + j * Dh + d];
+    sc[idx] = s * scale;
+  }
+  __syncthreads();
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wid; i < L; i += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sc[i * L + j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) { float e = expf(sc[i * L + j] - mx); sc[i * L + j] = e; sum += e; }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < L; j += 64) {
+      float pv = sc[i * L + j] * inv;
+      sc[i * L + j] = pv;
+      p[(int64_t)blockIdx.x * L * L + i * L + j] = pv;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {
+    int i = idx / Dh, d = idx - i * Dh;
+    float s = 0.f;
+    for (int j = 0; j < L; ++j) s += sc[i * L + j] * v[base + j * Dh + d];
+    o[base + idx] = s;
+  }
+}
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ q,
+                                                            const float* __restrict__ k, const float* __restrict__ v,
+                                                            const float* __restrict__ p, float* __restrict__ dq,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int L,
+                                                            int Dh) {
+  extern __shared__ float ds[];  // [L][L]
+  const int64_t base = (int64_t)blockIdx.x * L * Dh;
+  const float* pp = p + (int64_t)blockIdx.x * L * L;
+  const float scale = 1.0f / sqrtf((float)Dh);
+  for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {  // dV = P^T dO
+    int j = idx / Dh, d = idx - j * Dh;
+    float s = 0.f;
+    for (int i = 0; i < L; ++i) s += pp[i * L + j] * dO[base + i * Dh + d];
+    dv[base + idx] = s;
+  }
+  for (int idx = threadIdx.x; idx < L * L; idx += 256) {  // dP
+    int i = idx / L, j = idx - i * L;
+    float s = 0.f;
+    for (int d = 0; d < Dh; ++d) s += dO[base + i * Dh + d] * v[base + j * Dh + d];
+    ds[idx] = s;
+  }
+  __syncthreads();
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wid; i < L; i += 4) {
+    float dot = 0.f;
+    for (int j = lane; j < L; j += 64) dot += ds[i * L + j] * pp[i * L + j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < L; j += 64) ds[i * L + j] = pp[i * L + j] * (ds[i * L + j] - dot) * scale;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {
+    int i = idx / Dh, d = idx - i * Dh;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < L; ++j) {
+      s1 += ds[i * L + j] * k[base + j * Dh + d];   // dq[i]
+      s2 += ds[j * L + i] * q[base + j * Dh + d];   // dk[i]
+    }
+    dq[base + idx] = s1;
+    dk[base + idx] = s2;
+  }
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ void embedding_fwd_kernel(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E) {
+  EW_LOOP((int64_t)B * ncols * E) {
+    int e = (int)(i % E);
+    int64_t t = i / E;
+    int col = (int)(t % ncols);
+    int64_t id = ids[t];
+    if (id < 0) id = 0;
+    if (id >= card) id = card - 1;
+    out[i] = table[((int64_t)col * card + id) * E + e];
+  }
+}
+__global__ void embedding_bwd_kernel(const float* dout, const int64_t* ids, float* dtable, int B, int ncols, int card, int E) {
+  EW_LOOP((int64_t)ncols * card * E) {  // deterministic: each table element sums its own batch rows
+    int e = (int)(i % E);
+    int64_t t = i / E;
+    int id = (int)(t % card), col = (int)(t / card);
+    float s = 0.f;
+    for (int bb = 0; bb < B; ++bb)
+      if (ids[(int64_t)bb * ncols + col] == id) s += dout[((int64_t)bb * ncols + col) * E + e];
+    dtable[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------ custom-cnn direct kernels (NCHW)
+__global__ void direct_conv_fwd_kernel(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H,
+                                       int W, int Cout, int kh, int kw, int stride, int pad, int OH, int OW, int relu) {
+  EW_LOOP((int64_t)N * Cout * OH * OW) {
+    int ow = (int)(i % OW);
+    int64_t t = i / OW;
+    int oh = (int)(t % OH); t /= OH;
+    int co = (int)(t % Cout);
+    int n = (int)(t / Cout);
+    float s = b ? b[co] : 0.f;
+    for (int c = 0; c < Cin; ++c)
+      for (int r = 0; r < kh; ++r) {
+        int h = oh * stride - pad + r;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int q = 0; q < kw; ++q) {
+          int ww = ow * stride - pad + q;
+          if ((unsigned)ww >= (unsigned)W) continue;
+          s += x[(((int64_t)n * Cin + c) * H + h) * W + ww] * w[((co * Cin + c) * kh + r) * kw + q];
+        }
+      }
+    if (relu) s = fmaxf(s, 0.f);
+    y[i] = s;
+  }
+}
+// one workgroup per weight element (and one per bias): block-wide reduction over (n, oh, ow)
+__global__ __launch_bounds__(256) void direct_conv_bwd_kernel(const float* dy, const float* x, const float* y_relu,
+                                                              float* dw, float* db, int N, int Cin, int H, int W,
+                                                              int Cout, int kh, int kw, int stride, int pad, int OH,
+                                                              int OW) {
+  __shared__ float red[4];
+  const int nw = Cout * Cin * kh * kw;
+  const int id = blockIdx.x;
+  const bool is_bias = id >= nw;
+  int co, c = 0, r = 0, q = 0;
+  if (is_bias) co = id - nw;
+  else { q = id % kw; int t = id / kw; r = t % kh; t /= kh; c = t % Cin; co = t / Cin; }
+  float s = 0.f;
+  const int64_t total = (int64_t)N * OH * OW;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    int ow = (int)(i % OW);
+    int64_t t = i / OW;
+    int oh = (int)(t % OH);
+    int n = (int)(t / OH);
+    int64_t yo = (((int64_t)n * Cout + co) * OH + oh) * OW + ow;
+    float d = dy[yo];
+    if (y_relu && !(y_relu[yo] > 0.f)) d = 0.f;
+    if (is_bias) s += d;
+    else {
+      int h = oh * stride - pad + r, ww = ow * stride - pad + q;
+      if ((unsigned)h < (unsigned)H && (unsigned)ww < (unsigned)W) s += d * x[(((int64_t)n * Cin + c) * H + h) * W + ww];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = red[0] + red[1] + red[2] + red[3];
+    if (is_bias) { if (db) db[co] = tot; } else dw[id] = tot;
+  }
+}
+__global__ __launch_bounds__(64) void pool_gap_fwd_kernel(const float* x, float* y, int32_t* idx, int C, int H, int W,
+                                                          int k, int PH, int PW) {
+  const int nc = blockIdx.x;  // n*C + c
+  const float* xp = x + (int64_t)nc * H * W;
+  float s = 0.f;
+  for (int pi = threadIdx.x; pi < PH * PW; pi += 64) {
+    int ph = pi / PW, pw = pi - ph * PW;
+    float best = -INFINITY;
+    int bi = (ph * k) * W + pw * k;
+    for (int r = 0; r < k; ++r)
+      for (int q = 0; q < k; ++q) {
+        int h = ph * k + r, w = pw * k + q;
+        float v = xp[h * W + w];
+        if (v > best || v != v) { best = v; bi = h * W + w; }
+      }
+    idx[(int64_t)nc * PH * PW + pi] = bi;
+    s += best;
+  }
+  s = wave_sum(s);
+  if (threadIdx.x == 0) y[nc] = s / (float)(PH * PW);
+}
+__global__ void pool_gap_bwd_kernel(const float* dy, const int32_t* idx, float* dx, int64_t NC, int HW, int PHW) {
+  EW_LOOP(NC * PHW) {
+    int64_t nc = i / PHW;
+    dx[nc * HW + idx[i]] = dy[nc] / (float)PHW;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
+                          void* stream) {
+  ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+  return gemm_f32(x, w, y, b, M, N, K, K, 1, K, 1, N, relu, ST(stream));
+}
+
+int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
+                           float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
+  ARG_CHECK(dy && M > 0 && K > 0 && N > 0, "linear_backward: bad argument");
+  hipStream_t st = ST(stream);
+  const float* g = dy;
+  if (y_relu) {
+    ARG_CHECK(dy_scratch, "linear_backward: dy_scratch required with y_relu");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, dy, y_relu, dy_scratch, (int64_t)M * N);
+    HIP_CHECK_RET(hipGetLastError());
+    g = dy_scratch;
+  }
+  int rc;
+  if (dx) {  // dx[m][k] = sum_n g[m][n] * w[n][k]
+    ARG_CHECK(w, "linear_backward: w required for dx");
+    if ((rc = gemm_f32(g, w, dx, nullptr, M, K, N, N, 1, 1, K, K, 0, st))) return rc;
+  }
+  if (dw) {  // dw[n][k] = sum_m g[m][n] * x[m][k]
+    ARG_CHECK(x, "linear_backward: x required for dw");
+    if ((rc = gemm_f32(g, x, dw, nullptr, N, K, M, 1, N, 1, K, K, 0, st))) return rc;
+  }
+  if (db) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, g, db, M, N);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  return MMSKIN_OK;
+}
+
+int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
+                             int M, int N, float eps, int relu, void* stream) {
+  ARG_CHECK(x && g && b && y && mean && rstd && M > 0 && N > 0, "layernorm_forward: bad argument");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y, mean, rstd, M, N, eps, relu);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, const float* b, const float* mean,
+                              const float* rstd, float* dx, float* dg, float* db, int M, int N, int relu, void* stream) {
+  ARG_CHECK(dy && x && g && b && mean && rstd && M > 0 && N > 0, "layernorm_backward: bad argument");
+  if (dx) {
+    hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), dy, x, g, b, mean, rstd, dx, M, N, relu);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  if (dg || db) {
+    hipLaunchKernelGGL(layernorm_bwd_gb_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, ST(stream), dy, x, g, b, mean, rstd, dg, db, M, N, relu);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  return MMSKIN_OK;
+}
+
+#define EW_LAUNCH(kern, n, ...)                                                                  \
+  do {                                                                                           \
+    if ((n) > 0) {                                                                               \
+      hipLaunchKernelGGL(kern, dim3(grid1d(n)), dim3(256), 0, ST(stream), __VA_ARGS__);          \
+      HIP_CHECK_RET(hipGetLastError());                                                          \
+    }                                                                                            \
+    return MMSKIN_OK;                                                                            \
+  } while (0)
+
+int mmskin_sigmoid_gate_forward(const float* z, const float* v, float* out, int64_t n, void* stream) {
+  EW_LAUNCH(sigmoid_gate_fwd_kernel, n, z, v, out, n);
+}
+int mmskin_sigmoid_gate_backward(const float* dout, const float* z, const float* v, float* dz, float* dv, int64_t n, void* stream) {
+  EW_LAUNCH(sigmoid_gate_bwd_kernel, n, dout, z, v, dz, dv, n);
+}
+int mmskin_gated_mix_forward(const float* z, const float* a, const float* q, float* out, int64_t n, void* stream) {
+  EW_LAUNCH(gated_mix_fwd_kernel, n, z, a, q, out, n);
+}
+int mmskin_gated_mix_backward(const float* dout, const float* z, const float* a, const float* q, float* dz, float* da,
+                              float* dq, int64_t n, void* stream) {
+  EW_LAUNCH(gated_mix_bwd_kernel, n, dout, z, a, q, dz, da, dq, n);
+}
+int mmskin_metablock_gate_forward(const float* V, const float* t1, const float* t2, float* out, int64_t n, void* stream) {
+  EW_LAUNCH(metablock_gate_fwd_kernel, n, V, t1, t2, out, n);
+}
+int mmskin_metablock_gate_backward(const float* dout, const float* V, const float* t1, const float* t2, float* dV,
+                                   float* dt1, float* dt2, int64_t n, void* stream) {
+  EW_LAUNCH(metablock_gate_bwd_kernel, n, dout, V, t1, t2, dV, dt1, dt2, n);
+}
+int mmskin_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
+                           void* stream) {
+  EW_LAUNCH(dropout_fwd_kernel, n, x, y, mask, n, p, seed, offset);
+}
+int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
+  EW_LAUNCH(dropout_bwd_kernel, n, dy, mask, dx, n, p);
+}
+int mmskin_concat2_forward(const float* a, const float* b, float* out, int M, int Na, int Nb, void* stream) {
+  EW_LAUNCH(concat2_fwd_kernel, (int64_t)M * (Na + Nb), a, b, out, M, Na, Nb);
+}
+int mmskin_concat2_backward(const float* dout, float* da, float* db, int M, int Na, int Nb, void* stream) {
+  EW_LAUNCH(concat2_bwd_kernel, (int64_t)M * (Na + Nb), dout, da, db, M, Na, Nb);
+}
+
+int mmskin_attention_forward(const float* q, const float* k, const float* v, float* o, float* p, int B, int H, int L,
+                             int Dh, void* stream) {
+  ARG_CHECK(q && k && v && o && p && B > 0 && H > 0 && L > 0 && Dh > 0, "attention_forward: bad argument");
+  ARG_CHECK((size_t)L * L * 4 <= 64 * 1024, "attention_forward: L=%d too long for the small-attention kernel", L);
+  hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), q, k, v, o, p, L, Dh);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* p,
+                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, void* stream) {
+  ARG_CHECK(dO && q && k && v && p && dq && dk && dv, "attention_backward: null argument");
+  ARG_CHECK((size_t)L * L * 4 <= 64 * 1024, "attention_backward: L=%d too long", L);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), dO, q, k, v, p, dq, dk, dv, L, Dh);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
+                             void* stream) {
+  EW_LAUNCH(embedding_fwd_kernel, (int64_t)B * ncols * E, table, ids, out, B, ncols, card, E);
+}
+int mmskin_embedding_backward(const float* dout, const int64_t* ids, float* dtable, int B, int ncols, int card, int E,
+                              void* stream) {
+  EW_LAUNCH(embedding_bwd_kernel, (int64_t)ncols * card * E, dout, ids, dtable, B, ncols, card, E);
+}
+
+int mmskin_direct_conv2d_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,
+                                 int Cout, int kh, int kw, int stride, int pad, int relu, void* stream) {
+  int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
+  EW_LAUNCH(direct_conv_fwd_kernel, (int64_t)N * Cout * OH * OW, x, w, b, y, N, Cin, H, W, Cout, kh, kw, stride, pad, OH, OW, relu);
+}
+int mmskin_direct_conv2d_backward(const float* dy, const float* x, const float* y_relu, float* dw, float* db, int N,
+                                  int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, void* stream) {
+  ARG_CHECK(dy && x && dw, "direct_conv2d_backward: null argument");
+  int OH = (H + 2 * pad - kh) / stride + 1, OW = (W + 2 * pad - kw) / stride + 1;
+  int blocks = Cout * Cin * kh * kw + (db ? Cout : 0);
+  hipLaunchKernelGGL(direct_conv_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), dy, x, y_relu, dw, db, N, Cin, H, W,
+                     Cout, kh, kw, stride, pad, OH, OW);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_pool_gap_forward(const float* x, float* y, int32_t* idx, int N, int C, int H, int W, int k, void* stream) {
+  ARG_CHECK(x && y && idx && k > 0 && H >= k && W >= k, "pool_gap_forward: bad argument");
+  hipLaunchKernelGGL(pool_gap_fwd_kernel, dim3(N * C), dim3(64), 0, ST(stream), x, y, idx, C, H, W, k, H / k, W / k);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_pool_gap_backward(const float* dy, const int32_t* idx, float* dx, int N, int C, int H, int W, int k,
+                             void* stream) {
+  ARG_CHECK(dy && idx && dx, "pool_gap_backward: null argument");
+  HIP_CHECK_RET(hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), ST(stream)));
+  int64_t NC = (int64_t)N * C;
+  int PHW = (H / k) * (W / k);
+  EW_LAUNCH(pool_gap_bwd_kernel, NC * PHW, dy, idx, dx, NC, H * W, PHW);
+}
+
+}  // extern "C"

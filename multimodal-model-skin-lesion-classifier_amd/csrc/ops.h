@@ -1,0 +1,78 @@
+// HBM-bound NHWC kernels around the conv GEMMs: BatchNorm (train/eval, fwd/bwd), ReLU/residual,
+// stem packing + max-pool, global average pool, weight staging.  All loads/stores are 16 bytes per
+// lane; reductions are deterministic (per-block partial slabs + a finalize kernel, no atomics).
+#pragma once
+#include "common.h"
+
+// ---- BatchNorm forward
+// Reduce conv-epilogue partials [nrows][C] -> batch mean/var -> scale/shift (+ running stats).
+int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, double count,
+                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                hipStream_t st);
+int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, float* scale, float* shift, hipStream_t st);
+// y = [relu](x*scale[c] + shift[c] [+ res | + res*rscale[c] + rshift[c]]);  rows*C elements
+template <typename T>
+int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
+             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st);
+// Column partial sums of an arbitrary NHWC tensor (used where no conv epilogue produced them).
+template <typename T>
+int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq, int* nrows_out,
+                 hipStream_t st);
+int column_stats_rows(size_t rows, int C);
+
+// ---- BatchNorm backward
+enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2 };
+int bn_bwd_partial_rows(size_t rows, int C);
+// partial[blk][0][C] = sum dz, partial[blk][1][C] = sum dz*x   with dz = dy * mask
+template <typename T>
+int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
+                  int mask_mode, size_t rows, int C, float* partial, hipStream_t st);
+// -> dgamma, dbeta (may be null) and dx = cA*dz + cB*x + cC coefficient vectors
+int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                    float* cA, float* cB, float* cC, hipStream_t st);
+// dx = cA*dz + cB*x + cC ; optionally also writes dz (masked dy) to dz_out
+template <typename T>
+int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
+                 int mask_mode, const float* cA, const float* cB, const float* cC, T* dx, T* dz_out,
+                 size_t rows, int C, hipStream_t st);
+
+// ---- stem
+// NCHW fp32 image -> zero-padded NHWC4 T image [N][Hp][Wp][4] (3 px top/left border)
+template <typename T>
+int stem_pack(const float* img, int N, int H, int W, int Hp, int Wp, T* img4, hipStream_t st);
+// y = maxpool3x3s2p1(relu(x*scale+shift)); idx = argmax tap (first max, row-major), 0..8
+template <typename T>
+int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N, int H, int W, int C,
+                      T* y, uint8_t* idx, hipStream_t st);
+// dy_full[n][h][w][c] = sum over pooled windows whose argmax is (h,w) of dpool
+template <typename T>
+int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, T* dy_full, hipStream_t st);
+
+// ---- global average pool
+template <typename T>
+int avgpool_fwd(const T* x, int N, int HW, int C, float* feat, hipStream_t st);
+template <typename T>
+int avgpool_bwd(const float* dfeat, int N, int HW, int C, T* dx, hipStream_t st);
+
+// ---- weight staging (fp32 OIHW master weights -> T, K-contiguous GEMM operands)
+struct StageDesc {
+  int64_t src_off;   // element offset of the OIHW fp32 weight in the flat param buffer
+  int64_t fwd_off;   // element offset in the forward staging buffer  [Cout][taps][Cin]
+  int64_t dgrad_off; // element offset in the dgrad staging buffer    [Cin][taps][Cout]
+  int Cout, Cin, taps;
+  int stem;          // 1: conv1 7x7 -> virtual [64][8][32] (fwd only)
+};
+template <typename T>
+int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
+                  T* wdgrad, bool need_dgrad, hipStream_t st);
+// dwv[64][8][32] -> OIHW [64][3][7][7]
+int stem_wgrad_unpack(const float* dwv, float* dw, hipStream_t st);
+
+// ---- layout converters used by the op-level C ABI (tests / small tensors)
+template <typename T>
+int nchw_to_nhwc(const float* src, int N, int C, int H, int W, T* dst, hipStream_t st);
+template <typename T>
+int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream_t st);

@@ -1,0 +1,645 @@
+// HBM-bound NHWC kernels (see ops.h).  Replaces the ATen batch_norm / relu / add / max_pool2d /
+// adaptive_avg_pool2d forward+backward kernels the reference reaches through torchvision's ResNet
+// (multimodalIntraInterModal.py:167).
+#include "ops.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(size_t work_items) {
+  size_t b = (work_items + EW_BLOCK - 1) / EW_BLOCK;
+  if (b > 256 * 16) b = 256 * 16;  // grid-stride beyond 16 blocks per CU
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ column reduction geometry
+struct ColGeom {
+  int CPR;   // 16-byte chunks per row
+  int CW;    // chunk columns per block
+  int RL;    // row lanes per block
+  int RB;    // rows per block
+  int gx, gy;
+};
+static ColGeom col_geom(size_t rows, int C, int EPC) {
+  ColGeom g;
+  g.CPR = C / EPC;
+  g.CW = g.CPR >= 256 ? 256 : g.CPR;
+  g.RL = 256 / g.CW;
+  size_t rb = (rows + 1023) / 1024;
+  if (rb < (size_t)g.RL * 4) rb = (size_t)g.RL * 4;
+  rb = (rb + g.RL - 1) / g.RL * g.RL;
+  g.RB = (int)rb;
+  g.gx = (int)((rows + rb - 1) / rb);
+  g.gy = (g.CPR + g.CW - 1) / g.CW;
+  return g;
+}
+
+// Reduce NQ per-thread EPC-wide accumulators over the row lanes of a block and write them to
+// partial[(blockIdx.x*NQ + q)*C + channel].
+template <int EPC, int NQ>
+__device__ __forceinline__ void block_col_reduce(float (&acc)[NQ][EPC], int cx, int ry, int CW, int RL,
+                                                 int col, int CPR, int C, float* partial, float* red) {
+  // red: [NQ][RL][CW*EPC]
+  const bool active = ry < RL;
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) red[(q * RL + ry) * CW * EPC + cx * EPC + e] = acc[q][e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NQ * CW * EPC; i += blockDim.x) {
+    int q = i / (CW * EPC), ce = i - q * CW * EPC;
+    int ch = blockIdx.y * CW * EPC + ce;
+    if (ch < C) {
+      float s = 0.f;
+      for (int r = 0; r < RL; ++r) s += red[(q * RL + r) * CW * EPC + ce];
+      partial[((size_t)blockIdx.x * NQ + q) * C + ch] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BN forward
+__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nrows,
+                                   int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, float* scale, float* shift,
+                                   float* save_mean, float* save_invstd) {
+  __shared__ double red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = ry; r < nrows; r += 4) { s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c]; }
+  red[0][ry][cx] = s; red[1][ry][cx] = q;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+    q = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
+    if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
+    if (running_mean) {
+      double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, double count,
+                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, stat_sum, stat_sq, nrows, C,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
+                     save_invstd);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+  }
+}
+int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, float* scale, float* shift, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T, bool RELU, int RES>  // RES: 0 none, 1 plain residual, 2 residual*rscale + rshift
+__global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ rscale,
+                                                            const float* __restrict__ rshift, T* __restrict__ y,
+                                                            size_t nchunks, int CPR) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    int c0 = (int)(i % CPR) * EPC;
+    Chunk<T> v;
+    v.load(x + i * EPC);
+    Chunk<T> r;
+    if (RES) r.load(res + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float t = v.v[e] * scale[c0 + e] + shift[c0 + e];
+      if (RES == 1) t += r.v[e];
+      if (RES == 2) t += r.v[e] * rscale[c0 + e] + rshift[c0 + e];
+      if (RELU) t = fmaxf(t, 0.f);
+      v.v[e] = t;
+    }
+    v.store(y + i * EPC);
+  }
+}
+
+template <typename T>
+int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
+             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "bn_apply: C=%d", C);
+  size_t nch = rows * (C / EPC);
+  int grid = ew_grid(nch);
+  int mode = res ? (rscale ? 2 : 1) : 0;
+#define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, nch, C / EPC)
+  if (relu) { if (mode == 2) LAUNCH(true, 2); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 0); }
+  else { if (mode == 2) LAUNCH(false, 2); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 0); }
+#undef LAUNCH
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void column_stats_kernel(const T* __restrict__ x, size_t rows, int C,
+                                                           ColGeom g, float* partial_sum, float* partial_sq) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[2 * 256 * EPC];
+  const int cx = threadIdx.x % g.CW, ry = threadIdx.x / g.CW;
+  const int col = blockIdx.y * g.CW + cx;
+  float acc[2][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  if (ry < g.RL && col < g.CPR) {
+    size_t r_end = (size_t)(blockIdx.x + 1) * g.RB;
+    if (r_end > rows) r_end = rows;
+    for (size_t r = (size_t)blockIdx.x * g.RB + ry; r < r_end; r += g.RL) {
+      Chunk<T> v;
+      v.load(x + (r * g.CPR + col) * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { acc[0][e] += v.v[e]; acc[1][e] += v.v[e] * v.v[e]; }
+    }
+  }
+  // two quantities into two separate slabs: reuse the NQ=1 reducer twice
+  float a1[1][EPC], a2[1][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { a1[0][e] = acc[0][e]; a2[0][e] = acc[1][e]; }
+  block_col_reduce<EPC, 1>(a1, cx, ry, g.CW, g.RL, col, g.CPR, C, partial_sum, red);
+  __syncthreads();
+  block_col_reduce<EPC, 1>(a2, cx, ry, g.CW, g.RL, col, g.CPR, C, partial_sq, red);
+}
+
+int column_stats_rows(size_t rows, int C) {
+  ColGeom a = col_geom(rows, C, 4), b = col_geom(rows, C, 8);
+  return a.gx > b.gx ? a.gx : b.gx;
+}
+template <typename T>
+int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq, int* nrows_out,
+                 hipStream_t st) {
+  ARG_CHECK(C % DT<T>::EPC == 0, "column_stats: C=%d", C);
+  ColGeom g = col_geom(rows, C, DT<T>::EPC);
+  hipLaunchKernelGGL(column_stats_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, st, x, rows, C, g, stat_sum, stat_sq);
+  HIP_CHECK_RET(hipGetLastError());
+  *nrows_out = g.gx;
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ BN backward
+template <typename T, int MODE>
+__device__ __forceinline__ void masked_dy(Chunk<T>& dz, const Chunk<T>& xv, const T* ymask, size_t off,
+                                          const float* scale, const float* shift, int c0) {
+  constexpr int EPC = DT<T>::EPC;
+  if (MODE == MASK_FROM_X) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(xv.v[e] * scale[c0 + e] + shift[c0 + e] > 0.f)) dz.v[e] = 0.f;
+  } else if (MODE == MASK_FROM_Y) {
+    Chunk<T> yv;
+    yv.load(ymask + off);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(yv.v[e] > 0.f)) dz.v[e] = 0.f;
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ ymask,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, size_t rows, int C,
+                                                            ColGeom g, float* partial) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[2 * 256 * EPC];
+  const int cx = threadIdx.x % g.CW, ry = threadIdx.x / g.CW;
+  const int col = blockIdx.y * g.CW + cx;
+  float acc[2][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  if (ry < g.RL && col < g.CPR) {
+    size_t r_end = (size_t)(blockIdx.x + 1) * g.RB;
+    if (r_end > rows) r_end = rows;
+    const int c0 = col * EPC;
+    for (size_t r = (size_t)blockIdx.x * g.RB + ry; r < r_end; r += g.RL) {
+      size_t off = (r * g.CPR + col) * EPC;
+      Chunk<T> dz, xv;
+      dz.load(dy + off);
+      xv.load(x + off);
+      masked_dy<T, MODE>(dz, xv, ymask, off, scale, shift, c0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { acc[0][e] += dz.v[e]; acc[1][e] += dz.v[e] * xv.v[e]; }
+    }
+  }
+  block_col_reduce<EPC, 2>(acc, cx, ry, g.CW, g.RL, col, g.CPR, C, partial, red);
+}
+
+int bn_bwd_partial_rows(size_t rows, int C) { return column_stats_rows(rows, C); }
+
+template <typename T>
+int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
+                  int mask_mode, size_t rows, int C, float* partial, hipStream_t st) {
+  ARG_CHECK(C % DT<T>::EPC == 0, "bn_bwd_reduce: C=%d", C);
+  ColGeom g = col_geom(rows, C, DT<T>::EPC);
+#define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(g.gx, g.gy), dim3(256), 0, st, dy, x, ymask, scale, shift, rows, C, g, partial)
+  if (mask_mode == MASK_FROM_X) LAUNCH(MASK_FROM_X);
+  else if (mask_mode == MASK_FROM_Y) LAUNCH(MASK_FROM_Y);
+  else LAUNCH(MASK_NONE);
+#undef LAUNCH
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrows, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                       float* cA, float* cB, float* cC) {
+  __shared__ double red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int r = ry; r < nrows; r += 4) {
+      s1 += (double)partial[((size_t)r * 2) * C + c];
+      s2 += (double)partial[((size_t)r * 2 + 1) * C + c];
+    }
+  red[0][ry][cx] = s1; red[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    s1 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+    s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
+    double dg = is * (s2 - mu * s1);   // sum dz * xhat
+    if (dgamma) dgamma[c] = (float)dg;
+    if (dbeta) dbeta[c] = (float)s1;
+    double A = g * is;
+    cA[c] = (float)A;
+    cB[c] = (float)(-A * is * dg / count);
+    cC[c] = (float)(A * (-s1 / count + mu * is * dg / count));
+  }
+}
+
+int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
+                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                    float* cA, float* cB, float* cC, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
+                     gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T, int MODE, bool WRITE_DZ>
+__global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ ymask,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ cA,
+    const float* __restrict__ cB, const float* __restrict__ cC, T* __restrict__ dx, T* __restrict__ dz_out,
+    size_t nchunks, int CPR) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int c0 = (int)(i % CPR) * EPC;
+    const size_t off = i * EPC;
+    Chunk<T> dz, xv;
+    dz.load(dy + off);
+    xv.load(x + off);
+    masked_dy<T, MODE>(dz, xv, ymask, off, scale, shift, c0);
+    if (WRITE_DZ) dz.store(dz_out + off);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) xv.v[e] = cA[c0 + e] * dz.v[e] + cB[c0 + e] * xv.v[e] + cC[c0 + e];
+    xv.store(dx + off);
+  }
+}
+
+template <typename T>
+int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
+                 int mask_mode, const float* cA, const float* cB, const float* cC, T* dx, T* dz_out,
+                 size_t rows, int C, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "bn_bwd_apply: C=%d", C);
+  size_t nch = rows * (C / EPC);
+  int grid = ew_grid(nch);
+#define LAUNCH(M, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, W>), dim3(grid), dim3(EW_BLOCK), 0, st, dy, x, ymask, scale, shift, cA, cB, cC, dx, dz_out, nch, C / EPC)
+  if (mask_mode == MASK_FROM_X) { if (dz_out) LAUNCH(MASK_FROM_X, true); else LAUNCH(MASK_FROM_X, false); }
+  else if (mask_mode == MASK_FROM_Y) { if (dz_out) LAUNCH(MASK_FROM_Y, true); else LAUNCH(MASK_FROM_Y, false); }
+  else { if (dz_out) LAUNCH(MASK_NONE, true); else LAUNCH(MASK_NONE, false); }
+#undef LAUNCH
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ stem
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void stem_pack_kernel(const float* __restrict__ img, int N, int H, int W,
+                                                            int Hp, int Wp, T* __restrict__ out) {
+  const size_t total = (size_t)N * Hp * Wp;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int wp = (int)(i % Wp);
+    size_t t = i / Wp;
+    int hp = (int)(t % Hp), n = (int)(t / Hp);
+    int h = hp - 3, w = wp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      size_t base = ((size_t)n * 3 * H + h) * W + w;
+      v[0] = img[base]; v[1] = img[base + (size_t)H * W]; v[2] = img[base + 2 * (size_t)H * W];
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(out + i * 4) = make_float4(v[0], v[1], v[2], 0.f);
+    } else {
+      uint32_t lo = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+      uint32_t hi = f32_to_bf16_bits(v[2]);
+      *reinterpret_cast<uint2*>(out + i * 4) = make_uint2(lo, hi);
+    }
+  }
+}
+template <typename T>
+int stem_pack(const float* img, int N, int H, int W, int Hp, int Wp, T* img4, hipStream_t st) {
+  ARG_CHECK(Hp >= H + 6 && Wp >= W + 6 && Wp % 2 == 0, "stem_pack: bad padded size");
+  hipLaunchKernelGGL(stem_pack_kernel<T>, dim3(ew_grid((size_t)N * Hp * Wp)), dim3(EW_BLOCK), 0, st, img, N, H, W, Hp, Wp, img4);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void stem_bn_relu_pool_kernel(const T* __restrict__ x,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int N, int H,
+                                                                    int W, int C, int PH, int PW,
+                                                                    T* __restrict__ y, uint8_t* __restrict__ idx) {
+  constexpr int EPC = DT<T>::EPC;
+  const int CPR = C / EPC;
+  const size_t total = (size_t)N * PH * PW * CPR;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int cj = (int)(i % CPR);
+    size_t t = i / CPR;
+    int pw = (int)(t % PW); t /= PW;
+    int ph = (int)(t % PH);
+    int n = (int)(t / PH);
+    const int c0 = cj * EPC;
+    float best[EPC];
+    int bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        int h = 2 * ph - 1 + r, w = 2 * pw - 1 + s;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          Chunk<T> v;
+          v.load(x + (((size_t)n * H + h) * W + w) * C + c0);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float a = fmaxf(v.v[e] * scale[c0 + e] + shift[c0 + e], 0.f);
+            if (a > best[e] || bi[e] < 0 || a != a) { best[e] = a; bi[e] = r * 3 + s; }
+          }
+        }
+      }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = best[e];
+    o.store(y + i * EPC);
+    if constexpr (EPC == 8) {
+      uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+      uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+      *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+    } else {
+      *reinterpret_cast<uint32_t*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+  }
+}
+template <typename T>
+int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N, int H, int W, int C, T* y,
+                      uint8_t* idx, hipStream_t st) {
+  int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(stem_bn_relu_pool_kernel<T>, dim3(ew_grid((size_t)N * PH * PW * (C / DT<T>::EPC))),
+                     dim3(EW_BLOCK), 0, st, x, scale, shift, N, H, W, C, PH, PW, y, idx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const T* __restrict__ dpool,
+                                                              const uint8_t* __restrict__ idx, int N, int H, int W,
+                                                              int C, int PH, int PW, T* __restrict__ dy) {
+  constexpr int EPC = DT<T>::EPC;
+  const int CPR = C / EPC;
+  const size_t total = (size_t)N * H * W * CPR;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int cj = (int)(i % CPR);
+    size_t t = i / CPR;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int ph = h / 2; ph <= (h + 1) / 2; ++ph) {
+      if (ph >= PH) continue;
+      int r = h - (2 * ph - 1);
+      for (int pw = w / 2; pw <= (w + 1) / 2; ++pw) {
+        if (pw >= PW) continue;
+        int s = w - (2 * pw - 1);
+        const int tap = r * 3 + s;
+        size_t po = (((size_t)n * PH + ph) * PW + pw) * C + cj * EPC;
+        Chunk<T> g;
+        g.load(dpool + po);
+        uint32_t iw[2] = {0u, 0u};
+        if constexpr (EPC == 8) {
+          uint2 q = *reinterpret_cast<const uint2*>(idx + po);
+          iw[0] = q.x; iw[1] = q.y;
+        } else {
+          iw[0] = *reinterpret_cast<const uint32_t*>(idx + po);
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if ((int)((iw[e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += g.v[e];
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
+    o.store(dy + i * EPC);
+  }
+}
+template <typename T>
+int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, T* dy_full, hipStream_t st) {
+  int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / DT<T>::EPC))), dim3(EW_BLOCK),
+                     0, st, dpool, idx, N, H, W, C, PH, PW, dy_full);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ global average pool
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void avgpool_fwd_kernel(const T* __restrict__ x, int N, int HW, int C,
+                                                              float* __restrict__ feat) {
+  constexpr int EPC = DT<T>::EPC;
+  const int CPR = C / EPC;
+  const int total = N * CPR;
+  for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+    int n = i / CPR, cj = i - n * CPR;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      Chunk<T> v;
+      v.load(x + ((size_t)n * HW + p) * C + cj * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += v.v[e];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) feat[(size_t)n * C + cj * EPC + e] = acc[e] * inv;
+  }
+}
+template <typename T>
+int avgpool_fwd(const T* x, int N, int HW, int C, float* feat, hipStream_t st) {
+  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(ew_grid((size_t)N * (C / DT<T>::EPC))), dim3(EW_BLOCK), 0, st, x, N, HW, C, feat);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void avgpool_bwd_kernel(const float* __restrict__ dfeat, int N, int HW,
+                                                              int C, T* __restrict__ dx) {
+  constexpr int EPC = DT<T>::EPC;
+  const int CPR = C / EPC;
+  const size_t total = (size_t)N * HW * CPR;
+  const float inv = 1.f / (float)HW;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int cj = (int)(i % CPR);
+    int n = (int)(i / ((size_t)HW * CPR));
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = dfeat[(size_t)n * C + cj * EPC + e] * inv;
+    o.store(dx + i * EPC);
+  }
+}
+template <typename T>
+int avgpool_bwd(const float* dfeat, int N, int HW, int C, T* dx, hipStream_t st) {
+  hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * HW * (C / DT<T>::EPC))), dim3(EW_BLOCK), 0, st, dfeat, N, HW, C, dx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ weight staging
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc* __restrict__ table,
+                                                                const float* __restrict__ params,
+                                                                T* __restrict__ wfwd, T* __restrict__ wdgrad,
+                                                                int need_dgrad) {
+  const StageDesc d = table[blockIdx.y];
+  const int total = d.Cout * d.Cin * d.taps;
+  const float* src = params + d.src_off;
+  for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+    int o = i / (d.Cin * d.taps), rem = i - o * d.Cin * d.taps;
+    int c = rem / d.taps, t = rem - c * d.taps;
+    T v = from_f32<T>(src[i]);
+    if (d.stem) {
+      int r = t / 7, s = t - r * 7;  // 7x7 taps, Cin = 3 -> wv[o][r][s*4 + c]
+      wfwd[d.fwd_off + ((size_t)o * 8 + r) * 32 + s * 4 + c] = v;
+    } else {
+      wfwd[d.fwd_off + ((size_t)o * d.taps + t) * d.Cin + c] = v;
+      if (need_dgrad) wdgrad[d.dgrad_off + ((size_t)c * d.taps + t) * d.Cout + o] = v;
+    }
+  }
+}
+template <typename T>
+int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
+                  T* wdgrad, bool need_dgrad, hipStream_t st) {
+  int gx = ceil_div(max_elems, EW_BLOCK * 8);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(stage_weights_kernel<T>, dim3(gx, nlayers), dim3(EW_BLOCK), 0, st, table_dev, params, wfwd,
+                     wdgrad, need_dgrad ? 1 : 0);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+__global__ void stem_wgrad_unpack_kernel(const float* __restrict__ dwv, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 64*3*7*7
+  if (i < 64 * 147) {
+    int o = i / 147, rem = i - o * 147;
+    int c = rem / 49, t = rem - c * 49;
+    int r = t / 7, s = t - r * 7;
+    dw[i] = dwv[((size_t)o * 8 + r) * 32 + s * 4 + c];
+  }
+}
+int stem_wgrad_unpack(const float* dwv, float* dw, hipStream_t st) {
+  hipLaunchKernelGGL(stem_wgrad_unpack_kernel, dim3(ceil_div(64 * 147, 256)), dim3(256), 0, st, dwv, dw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ layout converters
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int N, int C, int H, int W, T* __restrict__ dst) {
+  const size_t total = (size_t)N * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    size_t t = i / C;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    dst[i] = from_f32<T>(src[(((size_t)n * C + c) * H + h) * W + w]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int N, int C, int H, int W, float* __restrict__ dst) {
+  const size_t total = (size_t)N * C * H * W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int w = (int)(i % W);
+    size_t t = i / W;
+    int h = (int)(t % H); t /= H;
+    int c = (int)(t % C);
+    int n = (int)(t / C);
+    dst[i] = to_f32(src[(((size_t)n * H + h) * W + w) * C + c]);
+  }
+}
+template <typename T>
+int nchw_to_nhwc(const float* src, int N, int C, int H, int W, T* dst, hipStream_t st) {
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, st, src, N, C, H, W, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, st, src, N, C, H, W, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+#define INST(T)                                                                                               \
+  template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t); \
+  template int column_stats<T>(const T*, size_t, int, float*, float*, int*, hipStream_t);                       \
+  template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, hipStream_t); \
+  template int bn_bwd_apply<T>(const T*, const T*, const T*, const float*, const float*, int, const float*, const float*, const float*, T*, T*, size_t, int, hipStream_t); \
+  template int stem_pack<T>(const float*, int, int, int, int, int, T*, hipStream_t);                            \
+  template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \
+  template int maxpool_bwd<T>(const T*, const uint8_t*, int, int, int, int, T*, hipStream_t);                   \
+  template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \
+  template int avgpool_bwd<T>(const float*, int, int, int, T*, hipStream_t);                                    \
+  template int stage_weights<T>(const StageDesc*, int, int, const float*, T*, T*, bool, hipStream_t);           \
+  template int nchw_to_nhwc<T>(const float*, int, int, int, int, T*, hipStream_t);                              \
+  template int nhwc_to_nchw<T>(const T*, int, int, int, int, float*, hipStream_t);
+INST(float)
+INST(bf16_t)

@@ -1,0 +1,309 @@
+// Weight-gradient GEMM for gfx950:  dW[cout][tap][c] = sum_m dY[m][cout] * gather(in)[m][tap][c]
+//
+// Replaces ATen/cuDNN conv_backward(weight) reached through the reference's torchvision backbone.
+// The reduction runs over pixels m, which is the *strided* dimension of both NHWC operands, so the
+// MFMA fragments (8 consecutive k per lane) need a transpose.  Tiles are staged in LDS exactly as
+// they sit in memory ([m][channel], 16-byte chunks, XOR-swizzled by row) and bf16 fragments are read
+// with ds_read_b64_tr_b16 (the CDNA4 transposing LDS read); the exact-f32 path reads one dword per
+// lane, which needs no transpose.  The pixel range is split over workgroups; every split writes its
+// own fp32 slab (deterministic, no atomics) and wgrad_reduce sums the slabs straight into the
+// OIHW gradient tensor.
+#include "conv.h"
+
+template <typename T> struct WG;
+template <> struct WG<bf16_t> { static constexpr int MS = 32; };
+template <> struct WG<float> { static constexpr int MS = 16; };
+
+// row swizzle (in 16-byte chunks) for a tile whose rows are PITCH bytes
+template <typename T, int PITCH> __device__ __forceinline__ int wg_swz(int row) {
+  if constexpr (sizeof(T) == 4) {
+    return (row & 1) << 2;
+  } else if constexpr (PITCH == 256) {
+    return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+  } else {
+    return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+  }
+}
+
+__device__ __forceinline__ uint2 lds_read_tr16_b64(const unsigned char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <typename T, int BO, int BKK>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+  constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS;
+  constexpr int PX = BO * (int)sizeof(T), PY = BKK * (int)sizeof(T);
+  constexpr int X_BYTES = MS * PX, Y_BYTES = MS * PY;
+  constexpr int CPR_X = BO / EPC, CPR_Y = BKK / EPC;  // chunks per row
+  constexpr int NX = MS * CPR_X / 256 > 0 ? MS * CPR_X / 256 : 1;
+  constexpr int NY = MS * CPR_Y / 256 > 0 ? MS * CPR_Y / 256 : 1;
+  static_assert(MS * CPR_X % 256 == 0 && MS * CPR_Y % 256 == 0, "tile/thread mismatch");
+  constexpr int FO = BO / 32, FK = BKK / 32;  // 16-wide fragments per wave (2x2 waves)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + Y_BYTES)];
+  unsigned char* Xs = smem;
+  unsigned char* Ys = smem + 2 * X_BYTES;
+
+  const int tid = threadIdx.x;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = tile % p.nblk_k; tile /= p.nblk_k;
+  const int ob = tile % p.nblk_o;
+  const int split = tile / p.nblk_o;
+  const int o0 = ob * BO, k0 = kb * BKK;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  // ---- X loader (dY rows): chunk idx = tid + 256*i
+  int x_row[NX], x_ch[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { int idx = tid + 256 * i; x_row[i] = idx / CPR_X; x_ch[i] = idx - x_row[i] * CPR_X; }
+  // ---- Y loader (gathered input rows)
+  int y_row[NY], y_ch[NY], y_c[NY], y_oy[NY], y_ox[NY], y_img[NY], y_dy[NY], y_dx[NY];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    int idx = tid + 256 * i;
+    y_row[i] = idx / CPR_Y; y_ch[i] = idx - y_row[i] * CPR_Y;
+    int kidx = k0 + y_ch[i] * EPC;
+    int tap = kidx / p.C;
+    y_c[i] = kidx - tap * p.C;
+    y_dy[i] = p.offy[tap]; y_dx[i] = p.offx[tap];
+    int m = m_begin + y_row[i];
+    int img = m / ohw, rem = m - img * ohw;
+    y_img[i] = img; y_oy[i] = rem / p.OW; y_ox[i] = rem - y_oy[i] * p.OW;
+  }
+  const unsigned char* dy_b = reinterpret_cast<const unsigned char*>(p.dy);
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+
+  uint4 rx[NX], ry[NY];
+  int m_stage = m_begin;  // first row of the stage the next load_stage() fetches
+  auto load_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int m = m_stage + x_row[i];
+      rx[i] = make_uint4(0, 0, 0, 0);
+      if (m < m_end)
+        rx[i] = *reinterpret_cast<const uint4*>(dy_b + ((size_t)m * p.Cout + o0 + x_ch[i] * EPC) * sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      int m = m_stage + y_row[i];
+      int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];
+      bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+      ry[i] = make_uint4(0, 0, 0, 0);
+      if (ok)
+        ry[i] = *reinterpret_cast<const uint4*>(
+            in_b + ((int64_t)((y_img[i] * p.IH + iy) * p.IW + ix) * p.Cpitch + y_c[i]) * (int)sizeof(T));
+      // advance this row's pixel by MS for the next stage
+      y_ox[i] += MS;
+      while (y_ox[i] >= p.OW) {
+        y_ox[i] -= p.OW;
+        if (++y_oy[i] == p.OH) { y_oy[i] = 0; ++y_img[i]; }
+      }
+    }
+    m_stage += MS;
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      *reinterpret_cast<uint4*>(Xs + buf * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = rx[i];
+#pragma unroll
+    for (int i = 0; i < NY; ++i)
+      *reinterpret_cast<uint4*>(Ys + buf * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = ry[i];
+  };
+
+  const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wo = wid >> 1, wk = wid & 1;  // wave position: cout half, k half
+  f32x4_t acc[FK][FO];
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FO; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nstage = (m_end - m_begin + MS - 1) / MS;
+  if (nstage > 0) { load_stage(); store_stage(0); }
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nstage) load_stage();
+    const unsigned char* Xb = Xs + cur * X_BYTES;
+    const unsigned char* Yb = Ys + cur * Y_BYTES;
+    if constexpr (sizeof(T) == 2) {
+      // transposing reads: lane (q,pp) of a 16-lane group addresses row q, columns 4pp..4pp+3 of a
+      // 4x16 block; lane i receives column i of the 4 rows.  Two reads give k = 8g .. 8g+7.
+      const int q = l15 >> 2, pp = l15 & 3;
+      uint4 fx[FO], fy[FK];
+#pragma unroll
+      for (int j = 0; j < FO; ++j) {
+        int colb = (wo * (BO / 2) + j * 16 + 4 * pp) * 2;  // byte offset in row
+        int r0 = 8 * g + q, r1 = r0 + 4;
+        uint2 lo = lds_read_tr16_b64(Xb + r0 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r0)) << 4) + (colb & 15));
+        uint2 hi = lds_read_tr16_b64(Xb + r1 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r1)) << 4) + (colb & 15));
+        fx[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int i = 0; i < FK; ++i) {
+        int colb = (wk * (BKK / 2) + i * 16 + 4 * pp) * 2;
+        int r0 = 8 * g + q, r1 = r0 + 4;
+        uint2 lo = lds_read_tr16_b64(Yb + r0 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r0)) << 4) + (colb & 15));
+        uint2 hi = lds_read_tr16_b64(Yb + r1 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r1)) << 4) + (colb & 15));
+        fy[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int i = 0; i < FK; ++i)
+#pragma unroll
+        for (int j = 0; j < FO; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fy[i]),
+                                                              __builtin_bit_cast(bf16x8_t, fx[j]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < MS / 4; ++ks) {
+        const int row = 4 * ks + g;
+        float fx[FO], fy[FK];
+#pragma unroll
+        for (int j = 0; j < FO; ++j) {
+          int col = wo * (BO / 2) + j * 16 + l15;
+          fx[j] = *reinterpret_cast<const float*>(Xb + row * PX + ((((col >> 2) ^ wg_swz<T, PX>(row)) << 4) | ((col & 3) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < FK; ++i) {
+          int col = wk * (BKK / 2) + i * 16 + l15;
+          fy[i] = *reinterpret_cast<const float*>(Yb + row * PY + ((((col >> 2) ^ wg_swz<T, PY>(row)) << 4) | ((col & 3) << 2)));
+        }
+#pragma unroll
+        for (int i = 0; i < FK; ++i)
+#pragma unroll
+          for (int j = 0; j < FO; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fx[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nstage) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[i = k index][j = cout]: lane holds cout = l15, k = g*4 + reg  -> float4 along k in the slab
+  float* slab = p.slab + (size_t)split * p.Cout * p.Ktot;
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FO; ++j) {
+      int cout = o0 + wo * (BO / 2) + j * 16 + l15;
+      int kidx = k0 + wk * (BKK / 2) + i * 16 + g * 4;
+      *reinterpret_cast<float4*>(slab + (size_t)cout * p.Ktot + kidx) =
+          make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+}
+
+// sum split slabs; write dw[(cout*C + c)*ntaps + tap]  (OIHW when tap = r*kw + s)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                    int Cout, int C, int ntaps) {
+  const int Ktot = C * ntaps;
+  const size_t total = (size_t)Cout * Ktot;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[k * total + i];
+    int cout = (int)(i / Ktot), kk = (int)(i - (size_t)cout * Ktot);
+    int tap = kk / C, c = kk - tap * C;
+    dw[((size_t)cout * C + c) * ntaps + tap] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps) {
+  BO = (Cout % 128 == 0) ? 128 : 64;
+  BKK = (Ktot % 128 == 0) ? 128 : 64;
+  int tiles = (Cout / BO) * (Ktot / BKK);
+  int want = ceil_div(1536, tiles);
+  int max_split = M / (MS * 4) > 0 ? M / (MS * 4) : 1;
+  nsplit = want < max_split ? want : max_split;
+  if (nsplit < 1) nsplit = 1;
+  mps = ceil_div(ceil_div(M, nsplit), MS) * MS;
+  nsplit = ceil_div(M, mps);
+}
+
+template <typename T>
+static size_t slab_bytes(int M, int Cout, int Ktot) {
+  int BO, BKK, ns, mps;
+  wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps);
+  return (size_t)ns * Cout * Ktot * sizeof(float);
+}
+size_t conv_wgrad_slab_bytes(const ConvShape& s) {
+  int M = s.N * s.OH() * s.OW(), K = s.kh * s.kw * s.Cin;
+  size_t a = slab_bytes<float>(M, s.Cout, K), b = slab_bytes<bf16_t>(M, s.Cout, K);
+  return a > b ? a : b;
+}
+size_t stem_wgrad_slab_bytes(int N, int OH, int OW) {
+  size_t a = slab_bytes<float>(N * OH * OW, 64, 256), b = slab_bytes<bf16_t>(N * OH * OW, 64, 256);
+  return a > b ? a : b;
+}
+
+template <typename T, int BO, int BKK>
+static int launch_wg(WgradArgs& a, hipStream_t st) {
+  a.nblk_o = a.Cout / BO;
+  a.nblk_k = a.Ktot / BKK;
+  int grid = a.nblk_o * a.nblk_k * a.nsplit;
+  hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK>), dim3(grid), dim3(256), 0, st, a);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_layout, hipStream_t st) {
+  ARG_CHECK(a.Cout % 64 == 0 && a.Ktot % 64 == 0, "wgrad: Cout=%d Ktot=%d must be multiples of 64", a.Cout, a.Ktot);
+  ARG_CHECK(a.C % DT<T>::EPC == 0, "wgrad: C=%d", a.C);
+  int BO, BKK;
+  wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
+  int rc;
+  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128>(a, st);
+  else if (BO == 128) rc = launch_wg<T, 128, 64>(a, st);
+  else if (BKK == 128) rc = launch_wg<T, 64, 128>(a, st);
+  else rc = launch_wg<T, 64, 64>(a, st);
+  if (rc) return rc;
+  size_t total = (size_t)a.Cout * a.Ktot;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.slab, dw, a.nsplit, a.Cout,
+                     C_for_layout, ntaps_for_layout);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw_oihw,
+                      hipStream_t st) {
+  ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "wgrad: too many taps");
+  WgradArgs a = {};
+  a.dy = dout; a.in = in; a.slab = slab;
+  a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
+  a.OH = s.OH(); a.OW = s.OW();
+  a.Cout = s.Cout; a.Ktot = s.kh * s.kw * s.Cin;
+  a.Sy = s.stride; a.Sx = s.stride; a.ntaps = s.kh * s.kw;
+  a.M = s.N * a.OH * a.OW;
+  for (int r = 0; r < s.kh; ++r)
+    for (int q = 0; q < s.kw; ++q) {
+      a.offy[r * s.kw + q] = (int8_t)(r - s.pad);
+      a.offx[r * s.kw + q] = (int8_t)(q - s.pad);
+    }
+  return run_wgrad<T>(a, dw_oihw, s.Cin, s.kh * s.kw, st);
+}
+
+template <typename T>
+int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout, const T* img4,
+                           float* slab, float* dwv, hipStream_t st) {
+  WgradArgs a = {};
+  a.dy = dout; a.in = img4; a.slab = slab;
+  a.N = N; a.IH = Hp; a.IW = Wp / 2; a.C = 32; a.Cpitch = 8;
+  a.OH = OH; a.OW = OW; a.Cout = 64; a.Ktot = 256;
+  a.Sy = 2; a.Sx = 1; a.ntaps = 8;
+  a.M = N * OH * OW;
+  for (int r = 0; r < 8; ++r) { a.offy[r] = (int8_t)r; a.offx[r] = 0; }
+  // layout trick: C=256, ntaps=1 makes the reducer write dwv[cout][256] unchanged
+  return run_wgrad<T>(a, dwv, 256, 1, st);
+}
+
+#define INST(T)                                                                                   \
+  template int launch_conv_wgrad<T>(const ConvShape&, const T*, const T*, float*, float*, hipStream_t); \
+  template int launch_stem_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t);
+INST(float)
+INST(bf16_t)

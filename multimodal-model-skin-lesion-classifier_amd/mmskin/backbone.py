@@ -1,0 +1,245 @@
+"""Image encoders on the HIP path.
+
+HipResNet mirrors torchvision's ResNet module tree (conv1/bn1/layerN.i.convK/bnK/downsample.{0,1})
+so that `image_encoder.*` state_dict keys match checkpoints trained with the reference
+(loadImageModelClassifier.py:65-75 builds torchvision models).  All parameters are views
+into ONE flat fp32 buffer and all BN running statistics into another; a whole forward (or
+backward) is a single C-ABI call into the plan executor (csrc/backbone.hip).
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+
+RESNET_DEPTHS = {"resnet-18": (False, (2, 2, 2, 2)), "resnet-50": (True, (3, 4, 6, 3))}
+_DTYPES = {"bf16": _lib.BF16, "bfloat16": _lib.BF16, "fp32": _lib.F32, "float32": _lib.F32}
+
+
+def default_compute_dtype():
+    return os.environ.get("MMSKIN_BACKBONE_DTYPE", "bf16").lower()
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, width, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, width, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, width, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(width, width, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.downsample = downsample
+
+
+class _Plan:
+    """Owns one C plan handle + its workspace for a fixed (batch, H, W, dtype, device)."""
+
+    def __init__(self, arch, N, H, W, dtype_id, device):
+        h = ctypes.c_void_p()
+        call("mmskin_backbone_create", arch.encode(), N, H, W, dtype_id, ctypes.byref(h))
+        self.handle = h
+        lib = _lib.load()
+        self.feat_dim = lib.mmskin_backbone_feature_dim(h)
+        self.param_numel = lib.mmskin_backbone_param_numel(h)
+        self.ws_bytes = lib.mmskin_backbone_workspace_bytes(h)
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device) if device is not None else None
+
+    def tensor_table(self, kind):
+        lib = _lib.load()
+        out = []
+        for i in range(lib.mmskin_backbone_num_tensors(self.handle, kind)):
+            name = ctypes.create_string_buffer(128)
+            off, numel, ndim = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+            shape = (ctypes.c_int64 * 4)()
+            call("mmskin_backbone_tensor_info", self.handle, kind, i, name, 128, ctypes.byref(off),
+                 ctypes.byref(numel), ctypes.byref(ndim), shape)
+            out.append((name.value.decode(), off.value, numel.value, tuple(shape[: ndim.value])))
+        return out
+
+    def __del__(self):
+        try:
+            _lib.load().mmskin_backbone_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, module, training, *params):
+        ops._need_gpu(image, "image_encoder")
+        image = image.float().contiguous()
+        N, _, H, W = image.shape
+        plan = module._plan_for(N, H, W, image.device)
+        feats = torch.empty((N, plan.feat_dim), device=image.device, dtype=torch.float32)
+        call("mmskin_backbone_forward", plan.handle, ptr(image), ptr(module._flat_p), ptr(module._flat_b),
+             ptr(plan.workspace), ptr(feats), int(training), stream())
+        ctx.plan = plan
+        ctx.module = module
+        ctx.training_fwd = training
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        module, plan = ctx.module, ctx.plan
+        if not ctx.training_fwd:
+            raise _lib.MMSkinError("image_encoder backward needs a training-mode forward (batch-stat BN)")
+        dfeat = dfeat.float().contiguous()
+        grads = torch.empty(plan.param_numel, device=dfeat.device, dtype=torch.float32)
+        call("mmskin_backbone_backward", plan.handle, ptr(dfeat), ptr(module._flat_p), ptr(plan.workspace), ptr(grads),
+             stream())
+        module.last_flat_grad = grads
+        out = [None, None, None]
+        for need, (off, numel, shape) in zip(ctx.needs_input_grad[3:], module._layout):
+            out.append(grads[off:off + numel].view(shape) if need else None)
+        return tuple(out)
+
+
+class HipResNet(nn.Module):
+    def __init__(self, name, compute_dtype=None):
+        super().__init__()
+        if name not in RESNET_DEPTHS:
+            raise ValueError(f"Backbone '{name}' não implementado.")
+        self.arch = name
+        self.compute_dtype = (compute_dtype or default_compute_dtype()).lower()
+        if self.compute_dtype not in _DTYPES:
+            raise ValueError(f"unknown compute dtype {self.compute_dtype}")
+        bottleneck, depths = RESNET_DEPTHS[name]
+        exp = 4 if bottleneck else 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = 64
+        for li, (width, nblk) in enumerate(zip((64, 128, 256, 512), depths), start=1):
+            blocks = []
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 1) else 1
+                cout = width * exp
+                ds = None
+                if stride != 1 or cin != cout:
+                    ds = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+                blocks.append((_Bottleneck if bottleneck else _BasicBlock)(cin, width, stride, ds))
+                cin = cout
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Identity()
+        self.num_features = cin
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._plans = {}
+        self._flat_p = None
+        self._flat_b = None
+        self._layout = None
+        self.last_flat_grad = None
+        self._repack()
+
+    # ------------------------------------------------------------------ flat parameter arena
+    def _bn_buffers(self):
+        for name, m in self.named_modules():
+            if isinstance(m, nn.BatchNorm2d):
+                yield name, m
+
+    @torch.no_grad()
+    def _repack(self):
+        params = list(self.parameters())
+        device = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        layout, off = [], 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off:off + n].view(p.shape)
+            layout.append((off, n, tuple(p.shape)))
+            off += n
+        bns = [m for _, m in self._bn_buffers()]
+        fb = torch.empty(sum(2 * m.num_features for m in bns), dtype=torch.float32, device=device)
+        off = 0
+        for m in bns:
+            for key in ("running_mean", "running_var"):
+                buf = getattr(m, key)
+                n = buf.numel()
+                fb[off:off + n].copy_(buf.reshape(-1).float())
+                m._buffers[key] = fb[off:off + n]
+                off += n
+        self._flat_p, self._flat_b, self._layout = flat, fb, layout
+        self._plans = {}
+
+    def _packed(self):
+        base = self._flat_p.data_ptr()
+        for p, (off, _, _) in zip(self.parameters(), self._layout):
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+        bb, off = self._flat_b.data_ptr(), 0
+        for _, m in self._bn_buffers():
+            for key in ("running_mean", "running_var"):
+                if getattr(m, key).data_ptr() != bb + 4 * off:
+                    return False
+                off += m.num_features
+        return True
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._repack()
+        return out
+
+    def _plan_for(self, N, H, W, device):
+        key = (N, H, W, self.compute_dtype, str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self.arch, N, H, W, _DTYPES[self.compute_dtype], device)
+            table = plan.tensor_table(0)
+            mine = [(n, off, numel, shape) for (n, _), (off, numel, shape) in
+                    zip(self.named_parameters(), self._layout)]
+            if [(t[0], t[1], t[2]) for t in table] != [(t[0], t[1], t[2]) for t in mine]:
+                raise _lib.MMSkinError("HipResNet parameter layout disagrees with the C plan")
+            if len(self._plans) >= 2:   # keep at most two shapes alive (train + ragged last batch)
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = plan
+        return plan
+
+    def forward(self, image):
+        if not self._packed():
+            self._repack()
+        training = self.training
+        feats = _BackboneFn.apply(image, self, training, *self.parameters())
+        if training:
+            torch._foreach_add_([m.num_batches_tracked for _, m in self._bn_buffers()], 1)
+        return feats
+
+
+class HipCustomCNN(nn.Sequential):
+    """loadImageModelClassifier.py:50-60: Conv(3,16,3,s2,p1)-ReLU-MaxPool2-GAP-Flatten-Linear(16,D)."""
+
+    def __init__(self, common_dim):
+        from .nn import FusedAway, HipLinear
+        super().__init__(
+            nn.Conv2d(3, 16, kernel_size=3, stride=2, padding=1),
+            FusedAway("ReLU"),
+            FusedAway("MaxPool2d(2)"),
+            FusedAway("AdaptiveAvgPool2d(1)"),
+            FusedAway("Flatten"),
+            HipLinear(16, common_dim),
+        )
+
+    def forward(self, x):
+        conv = self[0]
+        y = ops.direct_conv2d(x, conv.weight, conv.bias, 2, 1, True)
+        return self[5](ops.pool_gap(y, 2))

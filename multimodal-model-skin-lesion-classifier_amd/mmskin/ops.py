@@ -1,0 +1,347 @@
+"""autograd.Function wrappers over the C ABI (fp32 head operators + custom-cnn pieces).
+
+Each Function allocates its outputs with torch (device memory plumbing), launches
+the HIP kernels on torch's current stream through ctypes and keeps what the
+matching backward entry point needs.  No arithmetic happens in PyTorch here.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise _lib.MMSkinError(
+            f"mmskin.{what}: tensors must live on a HIP device (got {t.device}); the MI355X path has "
+            "no CPU fallback")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        _need_gpu(x, "linear")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w = _f32c(w)
+        M, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(y), M, K, N, int(relu), stream())
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = _f32c(dy).reshape(M, N)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_x else None
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b else None
+        scratch = torch.empty_like(dy2) if y is not None else None
+        call("mmskin_linear_backward", ptr(dy2), ptr(x2), ptr(w), ptr(y), ptr(scratch), ptr(dx), ptr(dw), ptr(db),
+             M, K, N, stream())
+        return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None
+
+
+def linear(x, w, b=None, relu=False):
+    return LinearFn.apply(x, w, b, relu)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim, optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps, relu):
+        _need_gpu(x, "layernorm")
+        N = x.shape[-1]
+        x2 = _f32c(x).reshape(-1, N)
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(M, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+        call("mmskin_layernorm_forward", ptr(x2), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), M, N, float(eps),
+             int(relu), stream())
+        ctx.save_for_backward(x2, g, b, mean, rstd)
+        ctx.relu = relu
+        ctx.xshape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, b, mean, rstd = ctx.saved_tensors
+        M, N = x2.shape
+        dy2 = _f32c(dy).reshape(M, N)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        dg = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        call("mmskin_layernorm_backward", ptr(dy2), ptr(x2), ptr(g), ptr(b), ptr(mean), ptr(rstd), ptr(dx), ptr(dg),
+             ptr(db), M, N, int(ctx.relu), stream())
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dg, db, None, None
+
+
+def layernorm(x, g, b, eps=1e-5, relu=False):
+    return LayerNormFn.apply(x, g, b, eps, relu)
+
+
+class SigmoidGateFn(torch.autograd.Function):
+    """sigmoid(z) * v."""
+
+    @staticmethod
+    def forward(ctx, z, v):
+        _need_gpu(z, "sigmoid_gate")
+        z, v = _f32c(z), _f32c(v)
+        out = torch.empty_like(z)
+        call("mmskin_sigmoid_gate_forward", ptr(z), ptr(v), ptr(out), z.numel(), stream())
+        ctx.save_for_backward(z, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, v = ctx.saved_tensors
+        dout = _f32c(dout)
+        dz, dv = torch.empty_like(z), torch.empty_like(v)
+        call("mmskin_sigmoid_gate_backward", ptr(dout), ptr(z), ptr(v), ptr(dz), ptr(dv), z.numel(), stream())
+        return dz, dv
+
+
+sigmoid_gate = SigmoidGateFn.apply
+
+
+class GatedMixFn(torch.autograd.Function):
+    """g*a + (1-g)*q with g = sigmoid(z)."""
+
+    @staticmethod
+    def forward(ctx, z, a, q):
+        _need_gpu(z, "gated_mix")
+        z, a, q = _f32c(z), _f32c(a), _f32c(q)
+        out = torch.empty_like(z)
+        call("mmskin_gated_mix_forward", ptr(z), ptr(a), ptr(q), ptr(out), z.numel(), stream())
+        ctx.save_for_backward(z, a, q)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, a, q = ctx.saved_tensors
+        dout = _f32c(dout)
+        dz, da, dq = torch.empty_like(z), torch.empty_like(a), torch.empty_like(q)
+        call("mmskin_gated_mix_backward", ptr(dout), ptr(z), ptr(a), ptr(q), ptr(dz), ptr(da), ptr(dq), z.numel(),
+             stream())
+        return dz, da, dq
+
+
+gated_mix = GatedMixFn.apply
+
+
+class MetaBlockGateFn(torch.autograd.Function):
+    """sigmoid(tanh(V*t1) + t2)."""
+
+    @staticmethod
+    def forward(ctx, V, t1, t2):
+        _need_gpu(V, "metablock_gate")
+        V, t1, t2 = _f32c(V), _f32c(t1), _f32c(t2)
+        out = torch.empty_like(V)
+        call("mmskin_metablock_gate_forward", ptr(V), ptr(t1), ptr(t2), ptr(out), V.numel(), stream())
+        ctx.save_for_backward(V, t1, t2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, t1, t2 = ctx.saved_tensors
+        dout = _f32c(dout)
+        dV, d1, d2 = torch.empty_like(V), torch.empty_like(t1), torch.empty_like(t2)
+        call("mmskin_metablock_gate_backward", ptr(dout), ptr(V), ptr(t1), ptr(t2), ptr(dV), ptr(d1), ptr(d2),
+             V.numel(), stream())
+        return dV, d1, d2
+
+
+metablock_gate = MetaBlockGateFn.apply
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        _need_gpu(x, "dropout")
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        call("mmskin_dropout_forward", ptr(x), ptr(y), ptr(mask), x.numel(), float(p), int(seed), int(offset), stream())
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(dy)
+        call("mmskin_dropout_backward", ptr(dy), ptr(mask), ptr(dx), dy.numel(), float(ctx.p), stream())
+        return dx, None, None, None
+
+
+_dropout_counter = [0]
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    # seed from torch's generator state so torch.manual_seed controls the masks
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    _dropout_counter[0] += x.numel()
+    return DropoutFn.apply(x, p, seed, _dropout_counter[0])
+
+
+class Concat2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, "concat2")
+        a, b = _f32c(a), _f32c(b)
+        M, Na = a.shape
+        Nb = b.shape[1]
+        out = torch.empty((M, Na + Nb), device=a.device, dtype=torch.float32)
+        call("mmskin_concat2_forward", ptr(a), ptr(b), ptr(out), M, Na, Nb, stream())
+        ctx.dims = (M, Na, Nb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        M, Na, Nb = ctx.dims
+        dout = _f32c(dout)
+        da = torch.empty((M, Na), device=dout.device, dtype=torch.float32)
+        db = torch.empty((M, Nb), device=dout.device, dtype=torch.float32)
+        call("mmskin_concat2_backward", ptr(dout), ptr(da), ptr(db), M, Na, Nb, stream())
+        return da, db
+
+
+concat2 = Concat2Fn.apply
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(Dh)) v on [B, H, L, Dh] tensors."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        _need_gpu(q, "attention")
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        B, H, L, Dh = q.shape
+        o = torch.empty_like(q)
+        p = torch.empty((B, H, L, L), device=q.device, dtype=torch.float32)
+        call("mmskin_attention_forward", ptr(q), ptr(k), ptr(v), ptr(o), ptr(p), B, H, L, Dh, stream())
+        ctx.save_for_backward(q, k, v, p)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, p = ctx.saved_tensors
+        B, H, L, Dh = q.shape
+        dO = _f32c(dO)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        call("mmskin_attention_backward", ptr(dO), ptr(q), ptr(k), ptr(v), ptr(p), ptr(dq), ptr(dk), ptr(dv), B, H, L,
+             Dh, stream())
+        return dq, dk, dv
+
+
+attention = AttentionFn.apply
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """table [ncols, card, E], ids [B, ncols] -> [B, ncols, E]."""
+
+    @staticmethod
+    def forward(ctx, table, ids):
+        _need_gpu(table, "embedding")
+        table = _f32c(table)
+        ids = ids.long().contiguous()
+        ncols, card, E = table.shape
+        B = ids.shape[0]
+        out = torch.empty((B, ncols, E), device=table.device, dtype=torch.float32)
+        call("mmskin_embedding_forward", ptr(table), ptr(ids), ptr(out), B, ncols, card, E, stream())
+        ctx.save_for_backward(ids)
+        ctx.dims = (B, ncols, card, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        B, ncols, card, E = ctx.dims
+        dout = _f32c(dout)
+        dtable = torch.empty((ncols, card, E), device=dout.device, dtype=torch.float32)
+        call("mmskin_embedding_backward", ptr(dout), ptr(ids), ptr(dtable), B, ncols, card, E, stream())
+        return dtable, None
+
+
+embedding = EmbeddingFn.apply
+
+
+class DirectConvFn(torch.autograd.Function):
+    """Small direct NCHW conv (+bias, optional ReLU) for the `custom-cnn` stem (no input gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        _need_gpu(x, "direct_conv2d")
+        x, w = _f32c(x), _f32c(w)
+        N, Cin, H, W = x.shape
+        Cout, _, kh, kw = w.shape
+        OH, OW = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        y = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+        call("mmskin_direct_conv2d_forward", ptr(x), ptr(w), ptr(b), ptr(y), N, Cin, H, W, Cout, kh, kw, stride, pad,
+             int(relu), stream())
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.cfg = (stride, pad, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        dy = _f32c(dy)
+        N, Cin, H, W = x.shape
+        Cout, _, kh, kw = w.shape
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if has_bias else None
+        call("mmskin_direct_conv2d_backward", ptr(dy), ptr(x), ptr(y), ptr(dw), ptr(db), N, Cin, H, W, Cout, kh, kw,
+             stride, pad, stream())
+        return None, dw, db, None, None, None
+
+
+direct_conv2d = DirectConvFn.apply
+
+
+class PoolGapFn(torch.autograd.Function):
+    """MaxPool2d(k) followed by AdaptiveAvgPool2d(1)+Flatten: [N,C,H,W] -> [N,C]."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        _need_gpu(x, "pool_gap")
+        x = _f32c(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, C, H // k, W // k), device=x.device, dtype=torch.int32)
+        call("mmskin_pool_gap_forward", ptr(x), ptr(y), ptr(idx), N, C, H, W, k, stream())
+        ctx.save_for_backward(idx)
+        ctx.cfg = (N, C, H, W, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W, k = ctx.cfg
+        dy = _f32c(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        call("mmskin_pool_gap_backward", ptr(dy), ptr(idx), ptr(dx), N, C, H, W, k, stream())
+        return dx, None
+
+
+pool_gap = PoolGapFn.apply
