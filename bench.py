@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one full training step (zero_grad -> forward -> weighted CE ->
+backward -> [gradient all-reduce] -> Adam) of ResNet-50 + one-hot metadata encoder + 'crossattention'
+fusion, batch 256 per GPU, bf16 backbone compute, synthetic 224x224x3 images + 20 metadata columns
+(BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded on the launch stream
+around every kernel of the dominant class (the implicit-GEMM convolution kernel, forward + dgrad);
+`cpu_baseline` times the CPU oracle (a port: the reference's Python never travels to the GPU box) on a
+bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multimodal-model-skin-lesion-classifier_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.nn as nn
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (chip table)
+PEAK_F32_TFLOPS = 157.3
+FLOP_PER_IMAGE = 24.33e9    # conv fwd 8.174 + bwd 16.113 + head 0.039 GFLOP
+CLASS_NAMES = ["conv_fwd", "conv_dgrad", "wgrad", "bn_fwd", "bn_bwd", "stage_weights", "stem_misc"]
+
+
+def build_model(device, dtype):
+    os.environ["MMSKIN_BACKBONE_DTYPE"] = dtype
+    from models import multimodalIntraInterModal as M
+    torch.manual_seed(0)
+    model = M.MultimodalModel(num_classes=6, num_heads=8, device=device, cnn_model_name="resnet-50",
+                              text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                              unfreeze_weights="unfrozen_weights", attention_mecanism="crossattention", n=2)
+    return model.to(device)
+
+
+def cpu_baseline(batch, seconds=12.0):
+    """fwd+bwd of the CPU oracle (fp32, all host threads) on batches of `batch` until ~`seconds` elapsed."""
+    from oracle.model import OracleMultimodalModel
+    # the GPU box exposes every host core but a 1-GPU job owns a 16-core share: do not oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
+    torch.manual_seed(0)
+    model = OracleMultimodalModel(num_classes=6, num_heads=8, device="cpu", cnn_model_name="resnet-50",
+                                  text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                                  unfreeze_weights="unfrozen_weights", attention_mecanism="crossattention", n=2)
+    model.train()
+    img, meta = torch.randn(batch, 3, 224, 224), torch.randn(batch, 20)
+    lab = torch.randint(0, 6, (batch,))
+    crit = nn.CrossEntropyLoss()
+    def step():
+        model.zero_grad(set_to_none=True)
+        crit(model(img, meta), lab).backward()
+    step()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(); n += 1
+        if time.perf_counter() - t0 > seconds or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * batch / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} fwd+bwd steps of batch {batch} (fp32, torch CPU oracle), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(device))   # "nccl" is RCCL on ROCm
+    from mmskin import _lib, dp
+
+    model = build_model(device, args.dtype)
+    if world > 1:
+        dp.broadcast_parameters(model)
+    model.train()
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    image = torch.randn(B, 3, 224, 224, generator=g).to(device)
+    meta = torch.randn(B, 20, generator=g).to(device)
+    label = torch.randint(0, 6, (B,), generator=g).to(device)
+    crit = nn.CrossEntropyLoss(weight=torch.tensor([0.6, 1.7, 0.9, 1.2, 0.4, 2.1], device=device))
+    opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)   # train_pad_20.py:54
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model(image, meta), label)
+        loss.backward()
+        if world > 1:
+            dp.allreduce_gradients(model, world)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(loss)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        plan = next(iter(model.image_encoder._plans.values()))
+        lib = _lib.load()
+        lib.mmskin_backbone_profile_enable(plan.handle, 1)
+        nprof = 3
+        for _ in range(nprof):
+            step()
+        ms, fl, by = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)()
+        ln = (ctypes.c_int64 * 7)()
+        _lib.check(lib.mmskin_backbone_profile_read(plan.handle, ms, fl, by, ln))
+        lib.mmskin_backbone_profile_enable(plan.handle, 0)
+        classes = {CLASS_NAMES[i]: {"ms_per_step": ms[i] / nprof, "launches_per_step": ln[i] // nprof,
+                                    "tflops": (fl[i] / nprof) / (ms[i] / nprof * 1e-3) / 1e12 if ms[i] > 0 and fl[i] > 0 else None,
+                                    "gbps": (by[i] / nprof) / (ms[i] / nprof * 1e-3) / 1e9 if ms[i] > 0 and by[i] > 0 else None}
+                   for i in range(7)}
+        # dominant kernel = conv_gemm_kernel (implicit GEMM): forward + dgrad launches
+        dom_ms = (ms[0] + ms[1]) / nprof
+        dom_fl = (fl[0] + fl[1]) / nprof
+        n_launch = (ln[0] + ln[1]) // nprof
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": None, "launches_per_step": int(n_launch),
+                    "avg_launch_us": round(dom_ms * 1e3 / max(n_launch, 1), 2),
+                    "algorithmic_gflop_per_launch": round(dom_fl / max(n_launch, 1) / 1e9, 3),
+                    "classes": classes}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "images/sec fwd+bwd, ResNet-50+crossattention bs=256",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "ResNet-50 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "weights": "random init (torchvision layout)", "unfreeze_weights": "unfrozen_weights"},
+            "step_tflops_per_gpu": round(ips / world * FLOP_PER_IMAGE / 1e12, 1),
+            "step_frac_of_peak": round(ips / world * FLOP_PER_IMAGE / 1e12 / peak, 4),
+            "loss": round(loss_val, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(32)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

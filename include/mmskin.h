@@ -44,6 +44,17 @@ int64_t mmskin_backbone_param_numel(mmskin_backbone_t h);
 int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h);
 int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h);
 int mmskin_backbone_feature_dim(mmskin_backbone_t h);
+/* Introspection for parity tests: where unit `index` (conv+BN, in parameter order) keeps its raw conv
+ * output x, its post-activation output y and its BN coefficient vectors inside the workspace.
+ * info12 = {x_off, y_off, coef_off (bytes), rows, Cout, OH, OW, Cin, H, W, pool_off, scratch0_off}. */
+int mmskin_backbone_num_units(mmskin_backbone_t h);
+int mmskin_backbone_unit_info(mmskin_backbone_t h, int index, char* name, int name_cap, int64_t* info12);
+/* Per-kernel-class timing with HIP events recorded on the launch stream (off by default).  Classes:
+ * 0 conv fwd (implicit GEMM), 1 conv dgrad, 2 wgrad(+reduce), 3 BN fwd (finalize+apply), 4 BN bwd,
+ * 5 weight staging, 6 stem pack/pool.  read() synchronises, returns the totals accumulated since
+ * enable()/the last read(): milliseconds, algorithmic FLOPs, algorithmic bytes, launches; then resets. */
+int mmskin_backbone_profile_enable(mmskin_backbone_t h, int on);
+int mmskin_backbone_profile_read(mmskin_backbone_t h, double* ms7, double* flops7, double* bytes7, int64_t* launches7);
 /* image_nchw: fp32 [batch,3,H,W]; features: fp32 [batch, feature_dim].  training!=0: batch-stat BN,
  * running stats updated in `buffers`, activations kept in `workspace` for the backward call. */
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,

@@ -43,7 +43,28 @@ struct Block {
   int in_C, in_H, in_W;
 };
 
+enum KClass { K_CONV_FWD = 0, K_CONV_DGRAD, K_WGRAD, K_BN_FWD, K_BN_BWD, K_STAGE, K_STEM_MISC, K_NCLASS };
+
+// Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
+// roofline).  Off by default: the timed region of a benchmark never pays for it.
+struct Profiler {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<int> cls;       // class of event pair i (events 2i, 2i+1)
+  size_t used = 0;
+  double flops[K_NCLASS] = {0};
+  double bytes[K_NCLASS] = {0};
+  hipEvent_t get() {
+    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
+    return pool[used++];
+  }
+  void begin(int c, hipStream_t st) { if (on) { cls.push_back(c); (void)hipEventRecord(get(), st); } }
+  void end(hipStream_t st) { if (on) (void)hipEventRecord(get(), st); }
+  void reset() { used = 0; cls.clear(); for (int i = 0; i < K_NCLASS; ++i) { flops[i] = 0; bytes[i] = 0; } }
+};
+
 struct Plan {
+  Profiler prof;
   int arch, N, H, W, dtype;
   int feat_dim;
   int Hp, Wp, OH0, OW0, PH, PW;
@@ -205,6 +226,19 @@ int build_plan(Plan& p) {
   return MMSKIN_OK;
 }
 
+#define PROF(cls_, flops_, bytes_, call_)                      \
+  do {                                                        \
+    p.prof.begin((cls_), st);                                 \
+    rc = (call_);                                             \
+    p.prof.end(st);                                           \
+    if (p.prof.on) { p.prof.flops[(cls_)] += (flops_); p.prof.bytes[(cls_)] += (bytes_); } \
+    if (rc) return rc;                                        \
+  } while (0)
+
+static inline double conv_flops(const ConvShape& s) {
+  return 2.0 * s.N * s.OH() * s.OW() * (double)s.Cout * s.Cin * s.kh * s.kw;
+}
+
 int ensure_table(Plan& p) {
   if (p.table_dev) return MMSKIN_OK;
   HIP_CHECK_RET(hipMalloc((void**)&p.table_dev, p.table_host.size() * sizeof(StageDesc)));
@@ -225,11 +259,13 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   if ((rc = ensure_table(p))) return rc;
   // stage weights (stem region needs zeros in its padding taps)
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
-  if ((rc = stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st))) return rc;
+  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st));
 
   auto bn_coeffs = [&](Unit& u, int stat_rows) -> int {
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
     const int C = u.s.Cout;
+    p.prof.begin(K_BN_FWD, st);
+    struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
     if (training)
       return bn_finalize(stat_sum, stat_sq, stat_rows, C, (double)u.rows(), params + u.g_off, params + u.b_off, eps,
                          mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C, st);
@@ -240,14 +276,15 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   // ---- stem
   Unit& u0 = p.units[0];
   T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
-  if ((rc = stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st))) return rc;
+  PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
-  if ((rc = launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
-                                    training ? stat_sum : nullptr, training ? stat_sq : nullptr, st))) return rc;
+  PROF(K_CONV_FWD, conv_flops(u0.s), 0.0,
+       launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
+                               training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
   if ((rc = bn_coeffs(u0, stem_conv_stat_rows(p.N, p.OH0, p.OW0)))) return rc;
   float* c0 = reinterpret_cast<float*>(ws + u0.coef_off);
   T* pool = reinterpret_cast<T*>(ws + p.off_pool);
-  if ((rc = stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st))) return rc;
+  PROF(K_STEM_MISC, 0.0, 0.0, stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st));
 
   // ---- residual stages
   for (Block& b : p.blocks) {
@@ -256,28 +293,30 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
     const int nu = (int)b.units.size();
     if (b.ds >= 0) {
       Unit& d = p.units[b.ds];
-      if ((rc = launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
-                                   training ? stat_sum : nullptr, training ? stat_sq : nullptr, st))) return rc;
+      PROF(K_CONV_FWD, conv_flops(d.s), 0.0,
+           launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
+                              training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
       if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
     }
     for (int i = 0; i < nu; ++i) {
       Unit& u = p.units[b.units[i]];
       T* x = reinterpret_cast<T*>(ws + u.x_off);
       T* y = reinterpret_cast<T*>(ws + u.y_off);
-      if ((rc = launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
-                                   training ? stat_sq : nullptr, st))) return rc;
+      PROF(K_CONV_FWD, conv_flops(u.s), 0.0,
+           launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
+                              training ? stat_sq : nullptr, st));
       if ((rc = bn_coeffs(u, conv_fwd_stat_rows(u.s)))) return rc;
       float* coef = reinterpret_cast<float*>(ws + u.coef_off);
       const int C = u.s.Cout;
       if (i + 1 < nu) {
-        if ((rc = bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st))) return rc;
+        PROF(K_BN_FWD, 0.0, 2.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
       } else if (b.ds >= 0) {
         Unit& d = p.units[b.ds];
         float* dc = reinterpret_cast<float*>(ws + d.coef_off);
-        if ((rc = bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(),
-                              C, true, st))) return rc;
+        PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T),
+             bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(), C, true, st));
       } else {
-        if ((rc = bn_apply<T>(x, in, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st))) return rc;
+        PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, in, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
       }
       cur = y;
     }
@@ -304,9 +343,12 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
     const T* x = reinterpret_cast<const T*>(ws + u.x_off);
     float* cB = cA + C; float* cC = cA + 2 * C;
-    int r;
-    if ((r = bn_bwd_reduce<T>(dy, x, ymask, coef, coef + C, mode, u.rows(), C, partial, st))) return r;
-    if ((r = bn_bwd_finalize(partial, bn_bwd_partial_rows(u.rows(), C), C, (double)u.rows(), params + u.g_off,
+    int r, nr = 0;
+    p.prof.begin(K_BN_BWD, st);
+    struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
+    if (p.prof.on) p.prof.bytes[K_BN_BWD] += (mode == MASK_FROM_Y ? 7.0 : 5.0) * u.rows() * C * sizeof(T);
+    if ((r = bn_bwd_reduce<T>(dy, x, ymask, coef, coef + C, mode, u.rows(), C, partial, &nr, st))) return r;
+    if ((r = bn_bwd_finalize(partial, nr, C, (double)u.rows(), params + u.g_off,
                              coef + 2 * C, coef + 3 * C, grads + u.g_off, grads + u.b_off, cA, cB, cC, st))) return r;
     return bn_bwd_apply<T>(dy, x, ymask, coef, coef + C, mode, cA, cB, cC, dx, dz, u.rows(), C, st);
   };
@@ -333,19 +375,20 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     for (int i = nu - 1; i >= 0; --i) {
       Unit& u = p.units[b.units[i]];
       const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
-      if ((rc = launch_conv_wgrad<T>(u.s, dX, uin, slab, grads + u.w_off, st))) return rc;
+      PROF(K_WGRAD, conv_flops(u.s), 0.0, launch_conv_wgrad<T>(u.s, dX, uin, slab, grads + u.w_off, st));
       if (i > 0) {
         Unit& up = p.units[b.units[i - 1]];
-        if ((rc = launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st))) return rc;
+        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st));
         if ((rc = bn_backward(up, dY, nullptr, MASK_FROM_X, dX, nullptr))) return rc;
       } else {
-        if ((rc = launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, has_ds ? (const T*)nullptr : dZ, st))) return rc;
+        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0,
+             launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, has_ds ? (const T*)nullptr : dZ, st));
       }
     }
     if (has_ds) {
       Unit& d = p.units[b.ds];
-      if ((rc = launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st))) return rc;
-      if ((rc = launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, gin, st))) return rc;
+      PROF(K_WGRAD, conv_flops(d.s), 0.0, launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st));
+      PROF(K_CONV_DGRAD, conv_flops(d.s), 0.0, launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, gin, st));
     }
     T* t = g; g = gin; gin = t;
   }
@@ -354,11 +397,12 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   Unit& u0 = p.units[0];
   T* dyfull = S[2];
   T* dx0 = S[3];
-  if ((rc = maxpool_bwd<T>(g, ws + p.off_idx, p.N, p.OH0, p.OW0, 64, dyfull, st))) return rc;
+  PROF(K_STEM_MISC, 0.0, 0.0, maxpool_bwd<T>(g, ws + p.off_idx, p.N, p.OH0, p.OW0, 64, dyfull, st));
   if ((rc = bn_backward(u0, dyfull, nullptr, MASK_FROM_X, dx0, nullptr))) return rc;
   float* dwv = reinterpret_cast<float*>(ws + p.off_dwv);
-  if ((rc = launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),
-                                      slab, dwv, st))) return rc;
+  PROF(K_WGRAD, conv_flops(u0.s), 0.0,
+       launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),
+                                 slab, dwv, st));
   return stem_wgrad_unpack(dwv, grads + u0.w_off, st);
 }
 
@@ -414,6 +458,41 @@ int64_t mmskin_backbone_param_numel(mmskin_backbone_t h) { return h->plan.param_
 int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h) { return h->plan.buffer_numel; }
 int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h) { return (int64_t)h->plan.ws_bytes; }
 int mmskin_backbone_feature_dim(mmskin_backbone_t h) { return h->plan.feat_dim; }
+
+int mmskin_backbone_profile_enable(mmskin_backbone_t h, int on) {
+  h->plan.prof.on = on != 0;
+  h->plan.prof.reset();
+  return MMSKIN_OK;
+}
+
+int mmskin_backbone_profile_read(mmskin_backbone_t h, double* ms7, double* flops7, double* bytes7, int64_t* launches7) {
+  Profiler& pr = h->plan.prof;
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  for (int c = 0; c < K_NCLASS; ++c) { ms7[c] = 0; flops7[c] = pr.flops[c]; bytes7[c] = pr.bytes[c]; launches7[c] = 0; }
+  for (size_t i = 0; i < pr.cls.size(); ++i) {
+    float ms = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&ms, pr.pool[2 * i], pr.pool[2 * i + 1]));
+    ms7[pr.cls[i]] += ms;
+    launches7[pr.cls[i]] += 1;
+  }
+  pr.reset();
+  return MMSKIN_OK;
+}
+
+int mmskin_backbone_num_units(mmskin_backbone_t h) { return (int)h->plan.units.size(); }
+
+int mmskin_backbone_unit_info(mmskin_backbone_t h, int index, char* name, int name_cap, int64_t* info12) {
+  ARG_CHECK(index >= 0 && index < (int)h->plan.units.size(), "unit_info: index %d out of range", index);
+  const Unit& u = h->plan.units[index];
+  // the conv weight is the unit's first parameter; find its name through the param table
+  for (const TensorInfo& t : h->plan.params)
+    if (t.offset == u.w_off && name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  const int64_t v[12] = {(int64_t)u.x_off, (int64_t)u.y_off, (int64_t)u.coef_off, (int64_t)u.rows(), u.s.Cout,
+                         u.s.OH(), u.s.OW(), u.s.Cin, u.s.H, u.s.W, (int64_t)h->plan.off_pool,
+                         (int64_t)h->plan.off_scratch[0]};
+  for (int i = 0; i < 12; ++i) info12[i] = v[i];
+  return MMSKIN_OK;
+}
 
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
                             void* workspace, float* features, int training, void* stream) {

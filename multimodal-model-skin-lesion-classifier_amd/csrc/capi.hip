@@ -130,8 +130,9 @@ int bn_bwd_op(const float* dy, const float* x, const float* gamma, const float* 
                      save_invstd, coef, coef + C);
   HIP_CHECK_RET(hipGetLastError());
   const int mode = relu ? MASK_FROM_X : MASK_NONE;
-  if ((rc = bn_bwd_reduce<T>(dyh, xh, nullptr, coef, coef + C, mode, rows, C, partial, st))) return rc;
-  if ((rc = bn_bwd_finalize(partial, bn_bwd_partial_rows(rows, C), C, (double)rows, gamma, save_mean, save_invstd,
+  int nr = 0;
+  if ((rc = bn_bwd_reduce<T>(dyh, xh, nullptr, coef, coef + C, mode, rows, C, partial, &nr, st))) return rc;
+  if ((rc = bn_bwd_finalize(partial, nr, C, (double)rows, gamma, save_mean, save_invstd,
                             dgamma, dbeta, coef + 2 * C, coef + 3 * C, coef + 4 * C, st))) return rc;
   if ((rc = bn_bwd_apply<T>(dyh, xh, nullptr, coef, coef + C, mode, coef + 2 * C, coef + 3 * C, coef + 4 * C, dxh,
                             (T*)nullptr, rows, C, st))) return rc;
@@ -211,8 +212,9 @@ int stem_bwd_op(const float* dy, const float* x, const float* w, const float* ga
   if ((rc = stem_fwd_core<T>(s, x, w, gamma, beta, N, H, W, eps, st))) return rc;
   if ((rc = nchw_to_nhwc<T>(dy, N, 64, g.PH, g.PW, s.dpool, st))) return rc;
   if ((rc = maxpool_bwd<T>(s.dpool, s.idx, N, g.OH, g.OW, 64, s.dyfull, st))) return rc;
-  if ((rc = bn_bwd_reduce<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, rows, 64, s.partial, st))) return rc;
-  if ((rc = bn_bwd_finalize(s.partial, bn_bwd_partial_rows(rows, 64), 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
+  int nr = 0;
+  if ((rc = bn_bwd_reduce<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, rows, 64, s.partial, &nr, st))) return rc;
+  if ((rc = bn_bwd_finalize(s.partial, nr, 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
                             dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, st))) return rc;
   if ((rc = bn_bwd_apply<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, s.coef + 256, s.coef + 320,
                             s.coef + 384, s.dx0, (T*)nullptr, rows, 64, st))) return rc;

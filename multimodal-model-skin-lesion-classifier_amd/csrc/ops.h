@@ -24,11 +24,11 @@ int column_stats_rows(size_t rows, int C);
 
 // ---- BatchNorm backward
 enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2 };
-int bn_bwd_partial_rows(size_t rows, int C);
+int bn_bwd_partial_rows(size_t rows, int C);  // upper bound over dtypes (for sizing only)
 // partial[blk][0][C] = sum dz, partial[blk][1][C] = sum dz*x   with dz = dy * mask
 template <typename T>
 int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
-                  int mask_mode, size_t rows, int C, float* partial, hipStream_t st);
+                  int mask_mode, size_t rows, int C, float* partial, int* nrows_out, hipStream_t st);
 // -> dgamma, dbeta (may be null) and dx = cA*dz + cB*x + cC coefficient vectors
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,

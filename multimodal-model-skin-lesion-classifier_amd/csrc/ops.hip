@@ -258,7 +258,7 @@ int bn_bwd_partial_rows(size_t rows, int C) { return column_stats_rows(rows, C);
 
 template <typename T>
 int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
-                  int mask_mode, size_t rows, int C, float* partial, hipStream_t st) {
+                  int mask_mode, size_t rows, int C, float* partial, int* nrows_out, hipStream_t st) {
   ARG_CHECK(C % DT<T>::EPC == 0, "bn_bwd_reduce: C=%d", C);
   ColGeom g = col_geom(rows, C, DT<T>::EPC);
 #define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(g.gx, g.gy), dim3(256), 0, st, dy, x, ymask, scale, shift, rows, C, g, partial)
@@ -267,6 +267,7 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
   else LAUNCH(MASK_NONE);
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
+  *nrows_out = g.gx;
   return MMSKIN_OK;
 }
 
@@ -631,7 +632,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
 #define INST(T)                                                                                               \
   template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t); \
   template int column_stats<T>(const T*, size_t, int, float*, float*, int*, hipStream_t);                       \
-  template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, hipStream_t); \
+  template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, int*, hipStream_t); \
   template int bn_bwd_apply<T>(const T*, const T*, const T*, const float*, const float*, int, const float*, const float*, const float*, T*, T*, size_t, int, hipStream_t); \
   template int stem_pack<T>(const float*, int, int, int, int, int, T*, hipStream_t);                            \
   template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \

@@ -33,6 +33,11 @@ _SIGNATURES = {
     "mmskin_backbone_buffer_numel": (_i64, [_P]),
     "mmskin_backbone_workspace_bytes": (_i64, [_P]),
     "mmskin_backbone_feature_dim": (_i, [_P]),
+    "mmskin_backbone_profile_enable": (_i, [_P, _i]),
+    "mmskin_backbone_profile_read": (_i, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                          ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
+    "mmskin_backbone_num_units": (_i, [_P]),
+    "mmskin_backbone_unit_info": (_i, [_P, _i, ctypes.c_char_p, _i, ctypes.POINTER(_i64)]),
     "mmskin_backbone_forward": (_i, [_P, _P, _P, _P, _P, _P, _i, _P]),
     "mmskin_backbone_backward": (_i, [_P, _P, _P, _P, _P, _P]),
     "mmskin_conv2d_workspace_bytes": (_i64, [_i] * 9),

@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads and exports everything include/mmskin.h declares; the drop-in
+modules mirror the reference's constructor / state_dict / error behaviour (no compute calls)."""
+import ctypes
+
+import pytest
+import torch
+
+from helpers import SMALL, golden
+from mmskin import _lib
+from models import multimodalIntraInterModal as M
+from models.loadImageModelClassifier import loadModels
+from oracle.backbones import OracleResNet
+from oracle.model import FUSION_STRINGS, OracleMultimodalModel
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _lib.declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mmskin.h but not exported"
+    assert set(names) == set(_lib._SIGNATURES), set(names) ^ set(_lib._SIGNATURES)
+    assert lib.mmskin_version() >= 100
+
+
+def test_plan_layout_without_gpu():
+    """backbone_create needs no GPU: the flat parameter layout is the torchvision named_parameters order."""
+    from mmskin.backbone import HipResNet, _Plan
+    for arch, feat in (("resnet-18", 512), ("resnet-50", 2048)):
+        plan = _Plan(arch, 2, 64, 64, _lib.BF16, None)
+        assert plan.feat_dim == feat
+        net = HipResNet(arch)
+        table = plan.tensor_table(0)
+        assert [t[0] for t in table] == [n for n, _ in net.named_parameters()]
+        assert [t[3] for t in table] == [tuple(p.shape) for p in net.parameters()]
+        assert plan.param_numel == sum(p.numel() for p in net.parameters())
+        # same names / shapes as the oracle restatement of torchvision's ResNet
+        ora = OracleResNet(arch)
+        assert [n for n, _ in ora.named_parameters()] == [t[0] for t in table]
+        bufs = [t[0] for t in plan.tensor_table(1)]
+        assert bufs == [n for n, _ in ora.named_buffers() if not n.endswith("num_batches_tracked")]
+        assert plan.ws_bytes > 0
+    with pytest.raises(_lib.MMSkinError):
+        _Plan("vgg16", 2, 64, 64, _lib.BF16, None)
+
+
+def test_state_dict_keys_and_seeded_init_match_reference():
+    gold = golden("seed_equivalence")
+    torch.manual_seed(1234)
+    m = M.MultimodalModel(**dict(SMALL, attention_mecanism="crossattention"))
+    sd = m.state_dict()
+    assert list(sd.keys()) == gold["keys"]
+    for k, s in gold["sums"].items():
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-6 * max(1.0, abs(s)), k
+
+
+@pytest.mark.parametrize("mech", FUSION_STRINGS)
+def test_constructor_matches_oracle_for_every_mechanism(mech):
+    kw = dict(SMALL, attention_mecanism=mech, n=1 if mech == "no-metadata" else 2)
+    a, b = M.MultimodalModel(**kw), OracleMultimodalModel(**kw)
+    assert [(k, tuple(v.shape)) for k, v in a.state_dict().items()] == \
+           [(k, tuple(v.shape)) for k, v in b.state_dict().items()]
+
+
+def test_resnet50_state_dict_matches_oracle_and_survives_to():
+    kw = dict(SMALL, cnn_model_name="resnet-50", common_dim=512, text_encoder_dim_output=512,
+              attention_mecanism="crossattention")
+    torch.manual_seed(7)
+    a = M.MultimodalModel(**kw)
+    torch.manual_seed(7)
+    b = OracleMultimodalModel(**kw)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k          # same seed => same init
+    assert sum(p.numel() for p in a.parameters()) == 36543320 + 0
+    enc = a.image_encoder
+    assert enc._packed()
+    a.double().float()                                 # _apply round trip keeps the flat arena
+    assert enc._packed()
+    a.load_state_dict(sb, strict=True)
+    assert enc._packed()
+    # positional ctor order (train_isic_2020.py:268 passes the first five positionally)
+    M.MultimodalModel(6, 8, "cpu", "custom-cnn", "one-hot-encoder")
+
+
+def test_error_conventions():
+    with pytest.raises(ValueError, match="Backbone 'nope' não implementado."):
+        loadModels.loadModelImageEncoder("nope", 64, "frozen_weights")
+    with pytest.raises(ValueError, match="Invalid backbone_train_mode: false"):
+        loadModels.loadModelImageEncoder("custom-cnn", 64, "false")
+    with pytest.raises(ValueError, match="Text encoder 'foo' não suportado."):
+        loadModels.loadTextModelEncoder("foo")
+    m = M.MultimodalModel(**dict(SMALL, attention_mecanism="concatenation"))
+    with pytest.raises(_lib.MMSkinError, match="no CPU fallback"):
+        m(torch.zeros(2, 3, 32, 32), torch.zeros(2, 20))
+
+
+def test_freeze_policy():
+    for mode, expect in (("frozen_weights", 0), ("unfrozen_weights", 159), ("last_layer_unfrozen_weights", 2)):
+        net, dim = loadModels.loadModelImageEncoder("resnet-50", 512, mode)
+        assert dim == 2048
+        assert sum(p.requires_grad for p in net.parameters()) == expect

@@ -1,0 +1,257 @@
+"""-m gpu: every HIP kernel behind the C ABI vs a plain PyTorch fp32 CPU reference of the same op.
+
+Tolerances (written per test) are on max|got-want| / rms(want): the exact-f32 MFMA path must agree to
+2e-4 (fp32 arithmetic, different summation order only); the bf16 path to 5e-2 -- bf16 storage rounds
+every element to 2^-9 relative, i.e. up to ~1% of the rms for the largest (4-5 sigma) elements, on top of
+the rounded operands.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, DT, conv_backward, conv_forward, rel_err, ws
+from mmskin import _lib, ops
+from mmskin._lib import call, ptr, stream
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp32": 2e-4, "bf16": 5e-2}
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 14, 14, 64, 1, 1, 0),      # layer1-style 1x1, BN=64 tile
+    (2, 64, 14, 14, 256, 1, 1, 0),     # expand 1x1, single K tile
+    (2, 256, 9, 11, 128, 1, 1, 0),     # odd spatial dims, ragged last row block
+    (3, 64, 12, 12, 64, 3, 1, 1),      # 3x3 stride 1
+    (2, 128, 14, 14, 128, 3, 2, 1),    # 3x3 stride 2 (dgrad parity classes)
+    (2, 128, 15, 13, 128, 3, 2, 1),    # 3x3 stride 2, odd sizes
+    (2, 256, 14, 14, 512, 1, 2, 0),    # downsample 1x1 stride 2
+    (1, 512, 7, 7, 512, 3, 1, 1),      # layer4-style, M < one row block
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward(case, dtype):
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y = conv_forward(x.to(DEV), w.to(DEV), stride, pad, dtype)
+    assert rel_err(y, y_ref) < TOL[dtype], ("fwd", rel_err(y, y_ref))
+    dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), stride, pad, dtype)
+    assert rel_err(dx, xr.grad) < TOL[dtype], ("dgrad", rel_err(dx, xr.grad))
+    assert rel_err(dw, wr.grad) < TOL[dtype], ("wgrad", rel_err(dw, wr.grad))
+
+
+def test_conv_rejects_unsupported_shapes():
+    x = torch.zeros(1, 3, 8, 8, device=DEV)
+    w = torch.zeros(16, 3, 3, 3, device=DEV)
+    with pytest.raises(_lib.MMSkinError):
+        conv_forward(x, w, 1, 1, "fp32")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("relu", [0, 1])
+@pytest.mark.parametrize("shape", [(4, 64, 9, 7), (2, 2048, 3, 3), (3, 256, 14, 14)])
+def test_batchnorm_train_forward_backward(shape, relu, dtype):
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(C + relu)
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    if dtype == "bf16":
+        x = x.bfloat16().float()     # bf16-representable input: the reference sees what the kernel stores
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = torch.randn(shape, generator=g)
+    if dtype == "bf16":
+        dy = dy.bfloat16().float()
+    y_ref.backward(dy)
+    lib = _lib.load()
+    wsp = ws(lib.mmskin_batchnorm_workspace_bytes(N, C, H, W))
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    y, sm, si = torch.empty_like(xd), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("mmskin_batchnorm_forward", ptr(xd), ptr(gd), ptr(bd), ptr(rmd), ptr(rvd), ptr(y), ptr(sm), ptr(si), N, C, H,
+         W, 1e-5, 0.1, relu, DT[dtype], ptr(wsp), stream())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel_err(y, y_ref) < tol
+    assert rel_err(rmd, rm) < tol and rel_err(rvd, rv) < tol          # running stats (updated in place by F.batch_norm)
+    dx, dg, db = torch.empty_like(xd), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    call("mmskin_batchnorm_backward", ptr(dy.to(DEV)), ptr(xd), ptr(gd), ptr(bd), ptr(sm), ptr(si), ptr(dx), ptr(dg),
+         ptr(db), N, C, H, W, relu, DT[dtype], ptr(wsp), stream())
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad) < 3 * tol, rel_err(dx, xr.grad)
+    assert rel_err(dg, gr.grad) < 3 * tol and rel_err(db, br.grad) < 3 * tol
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("hw", [(64, 64), (48, 80)])
+def test_stem_forward_backward(hw, dtype):
+    """conv7x7/2 + BN(train) + ReLU + maxpool3x3/2, incl. the padded-NHWC4 'virtual conv' trick."""
+    H, W = hw
+    N = 3
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    wr, gr, br = (t.clone().requires_grad_(True) for t in (w, gamma, beta))
+    z = F.conv2d(x, wr, stride=2, padding=3)
+    z = F.relu(F.batch_norm(z, None, None, gr, br, training=True, eps=1e-5))
+    y_ref = F.max_pool2d(z, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    lib = _lib.load()
+    wsp = ws(lib.mmskin_stem_workspace_bytes(N, H, W))
+    y = torch.empty(y_ref.shape, device=DEV)
+    args = (ptr(x.to(DEV)), ptr(w.to(DEV)), ptr(gamma.to(DEV)), ptr(beta.to(DEV)))
+    keep = [x.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV)]
+    args = tuple(ptr(t) for t in keep)
+    call("mmskin_stem_forward", *args, ptr(y), N, H, W, 1e-5, DT[dtype], ptr(wsp), stream())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert rel_err(y, y_ref) < tol, rel_err(y, y_ref)
+    dw, dg, db = torch.empty(64, 3, 7, 7, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    dyd = dy.to(DEV)
+    call("mmskin_stem_backward", ptr(dyd), *args, ptr(dw), ptr(dg), ptr(db), N, H, W, 1e-5, DT[dtype], ptr(wsp),
+         stream())
+    torch.cuda.synchronize()
+    if dtype == "fp32":
+        assert rel_err(dw, wr.grad) < 3 * tol, rel_err(dw, wr.grad)
+        assert rel_err(dg, gr.grad) < 3 * tol and rel_err(db, br.grad) < 3 * tol
+    else:
+        # bf16: the conv output is rounded before BN/ReLU/max-pool, so a few activations land on the other
+        # side of 0 or hand the pooling window to a neighbour; each flip moves one gradient entry by O(1).
+        # Those are sparse, so the check is in relative L2 rather than max-norm.
+        l2 = lambda a, b: float((a.cpu().double() - b.double()).norm() / b.double().norm())
+        assert l2(dw, wr.grad) < 0.1, l2(dw, wr.grad)
+        assert l2(dg, gr.grad) < 0.1 and l2(db, br.grad) < 0.1
+
+
+# ------------------------------------------------------------------------------- head operators
+def _chk(got, want, tol=2e-5):
+    if float((got.detach().cpu().double() - want.detach().double()).abs().max()) < 1e-6:
+        return               # mathematically-zero gradients (e.g. softmax over one key): absolute check
+    assert rel_err(got, want) < tol, rel_err(got, want)
+
+
+@pytest.mark.parametrize("M,K,N", [(4, 20, 256), (256, 512, 512), (7, 85, 64), (130, 1024, 6), (33, 2048, 512)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_linear(M, K, N, relu):
+    g = torch.Generator().manual_seed(M * N)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.linear(xr, wr, br)
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = torch.randn(M, N, generator=g)
+    y_ref.backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, relu)
+    y.backward(dy.to(DEV))
+    _chk(y, y_ref); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad); _chk(bd.grad, br.grad)
+
+
+@pytest.mark.parametrize("M,N", [(4, 64), (256, 512), (9, 2048), (5, 32)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layernorm(M, N, relu):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g) * 3 + 1; w = torch.rand(N, generator=g) + 0.5; b = torch.randn(N, generator=g) * 0.2
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.layer_norm(xr, (N,), wr, br)
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = torch.randn(M, N, generator=g)
+    y_ref.backward(dy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.layernorm(xd, wd, bd, 1e-5, relu)
+    y.backward(dy.to(DEV))
+    _chk(y, y_ref); _chk(xd.grad, xr.grad, 1e-4); _chk(wd.grad, wr.grad, 1e-4); _chk(bd.grad, br.grad, 1e-4)
+
+
+def test_pointwise_gates():
+    g = torch.Generator().manual_seed(3)
+    a, b, c = (torch.randn(37, 64, generator=g) for _ in range(3))
+    dy = torch.randn(37, 64, generator=g)
+    for name, fn_ref, fn in (
+        ("sigmoid_gate", lambda z, v: torch.sigmoid(z) * v, ops.sigmoid_gate),
+        ("gated_mix", lambda z, p, q: torch.sigmoid(z) * p + (1 - torch.sigmoid(z)) * q, ops.gated_mix),
+        ("metablock_gate", lambda V, t1, t2: torch.sigmoid(torch.tanh(V * t1) + t2), ops.metablock_gate),
+    ):
+        nargs = 2 if name == "sigmoid_gate" else 3
+        ref_in = [t.clone().requires_grad_(True) for t in (a, b, c)[:nargs]]
+        dev_in = [t.to(DEV).requires_grad_(True) for t in (a, b, c)[:nargs]]
+        yr = fn_ref(*ref_in); yr.backward(dy)
+        yd = fn(*dev_in); yd.backward(dy.to(DEV))
+        _chk(yd, yr)
+        for r, d in zip(ref_in, dev_in):
+            _chk(d.grad, r.grad)
+
+
+def test_concat_dropout_embedding():
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(6, 10, generator=g), torch.randn(6, 7, generator=g)
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.concat2(ad, bd)
+    assert torch.equal(y.cpu(), torch.cat([a, b], 1))
+    dy = torch.randn(6, 17, generator=g)
+    y.backward(dy.to(DEV))
+    assert torch.equal(ad.grad.cpu(), dy[:, :10]) and torch.equal(bd.grad.cpu(), dy[:, 10:])
+    # dropout: inverted scaling, mask reused in backward, keep-rate close to 1-p, eval = identity
+    x = torch.ones(400, 500, device=DEV, requires_grad=True)
+    y = ops.dropout(x, 0.3, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.7, device=DEV))
+    y.sum().backward()
+    assert torch.equal((x.grad != 0), (y != 0))
+    assert ops.dropout(x, 0.3, False) is x
+    # embedding
+    table = torch.randn(5, 10, 8, generator=g)
+    ids = torch.randint(0, 10, (9, 5), generator=g)
+    tr = table.clone().requires_grad_(True)
+    ref = torch.stack([tr[c][ids[:, c]] for c in range(5)], dim=1)
+    dyo = torch.randn(9, 5, 8, generator=g)
+    ref.backward(dyo)
+    td = table.to(DEV).requires_grad_(True)
+    out = ops.embedding(td, ids.to(DEV))
+    out.backward(dyo.to(DEV))
+    _chk(out, ref); _chk(td.grad, tr.grad)
+
+
+@pytest.mark.parametrize("B,H,L,Dh", [(3, 4, 82, 8), (2, 8, 1, 64), (2, 2, 17, 16)])
+def test_attention(B, H, L, Dh):
+    g = torch.Generator().manual_seed(L)
+    q, k, v = (torch.randn(B, H, L, Dh, generator=g) for _ in range(3))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qr, kr, vr)
+    dO = torch.randn(B, H, L, Dh, generator=g)
+    ref.backward(dO)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention(qd, kd, vd)
+    out.backward(dO.to(DEV))
+    _chk(out, ref, 1e-4); _chk(qd.grad, qr.grad, 1e-4); _chk(kd.grad, kr.grad, 1e-4); _chk(vd.grad, vr.grad, 1e-4)
+
+
+def test_custom_cnn_pieces():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3, 32, 32, generator=g)
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.2; b = torch.randn(16, generator=g) * 0.1
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.adaptive_avg_pool2d(F.max_pool2d(F.relu(F.conv2d(x, wr, br, stride=2, padding=1)), 2), 1).flatten(1)
+    dy = torch.randn(3, 16, generator=g)
+    ref.backward(dy)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.pool_gap(ops.direct_conv2d(x.to(DEV), wd, bd, 2, 1, True), 2)
+    out.backward(dy.to(DEV))
+    _chk(out, ref); _chk(wd.grad, wr.grad, 1e-4); _chk(bd.grad, br.grad, 1e-4)
