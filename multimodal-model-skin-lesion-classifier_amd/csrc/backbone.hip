@@ -79,7 +79,7 @@ struct Plan {
   // workspace layout (bytes)
   size_t ws_bytes = 0;
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[6], off_slab, off_partial,
-      off_coefbwd, off_dwv;
+      off_coefbwd, off_dwv, off_red;
   size_t maxact_bytes = 0, stat_bytes = 0;
   size_t esz() const { return dtype == 1 ? 2 : 4; }
 };
@@ -222,6 +222,7 @@ int build_plan(Plan& p) {
   p.off_partial = carve(cur, partial_max);
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
+  p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.ws_bytes = cur;
   return MMSKIN_OK;
 }
@@ -268,7 +269,8 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
     struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
     if (training)
       return bn_finalize(stat_sum, stat_sq, stat_rows, C, (double)u.rows(), params + u.g_off, params + u.b_off, eps,
-                         mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C, st);
+                         mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C,
+                         reinterpret_cast<double*>(ws + p.off_red), st);
     return bn_eval_coeffs(C, params + u.g_off, params + u.b_off, buffers + u.rm_off, buffers + u.rv_off, eps, coef,
                           coef + C, st);
   };
@@ -349,7 +351,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     if (p.prof.on) p.prof.bytes[K_BN_BWD] += (mode == MASK_FROM_Y ? 7.0 : 5.0) * u.rows() * C * sizeof(T);
     if ((r = bn_bwd_reduce<T>(dy, x, ymask, coef, coef + C, mode, u.rows(), C, partial, &nr, st))) return r;
     if ((r = bn_bwd_finalize(partial, nr, C, (double)u.rows(), params + u.g_off,
-                             coef + 2 * C, coef + 3 * C, grads + u.g_off, grads + u.b_off, cA, cB, cC, st))) return r;
+                             coef + 2 * C, coef + 3 * C, grads + u.g_off, grads + u.b_off, cA, cB, cC,
+                             reinterpret_cast<double*>(ws + p.off_red), st))) return r;
     return bn_bwd_apply<T>(dy, x, ymask, coef, coef + C, mode, cA, cB, cC, dx, dz, u.rows(), C, st);
   };
 

@@ -105,7 +105,7 @@ int bn_fwd_op(const float* x, const float* gamma, const float* beta, float* rm, 
   if ((rc = nchw_to_nhwc<T>(x, N, C, H, W, xh, st))) return rc;
   if ((rc = column_stats<T>(xh, rows, C, ssum, ssq, &nr, st))) return rc;
   if ((rc = bn_finalize(ssum, ssq, nr, C, (double)rows, gamma, beta, eps, mom, rm, rv, coef, coef + C, save_mean,
-                        save_invstd, st))) return rc;
+                        save_invstd, nullptr, st))) return rc;
   if ((rc = bn_apply<T>(xh, nullptr, coef, coef + C, nullptr, nullptr, yh, rows, C, relu != 0, st))) return rc;
   return nhwc_to_nchw<T>(yh, N, C, H, W, y, st);
 }
@@ -133,7 +133,7 @@ int bn_bwd_op(const float* dy, const float* x, const float* gamma, const float* 
   int nr = 0;
   if ((rc = bn_bwd_reduce<T>(dyh, xh, nullptr, coef, coef + C, mode, rows, C, partial, &nr, st))) return rc;
   if ((rc = bn_bwd_finalize(partial, nr, C, (double)rows, gamma, save_mean, save_invstd,
-                            dgamma, dbeta, coef + 2 * C, coef + 3 * C, coef + 4 * C, st))) return rc;
+                            dgamma, dbeta, coef + 2 * C, coef + 3 * C, coef + 4 * C, nullptr, st))) return rc;
   if ((rc = bn_bwd_apply<T>(dyh, xh, nullptr, coef, coef + C, mode, coef + 2 * C, coef + 3 * C, coef + 4 * C, dxh,
                             (T*)nullptr, rows, C, st))) return rc;
   return nhwc_to_nchw<T>(dxh, N, C, H, W, dx, st);
@@ -154,7 +154,7 @@ struct StemGeom {
 template <typename T>
 struct StemWs {
   StageDesc* table; T* img4; T* wv; T* x0; T* pool; uint8_t* idx; float* ssum; float* ssq; float* coef;
-  T* dpool; T* dyfull; T* dx0; float* partial; float* slab; float* dwv;
+  T* dpool; T* dyfull; T* dx0; float* partial; float* slab; float* dwv; double* red;
   StemWs(void* ws, int N, int H, int W) {
     StemGeom g(H, W);
     Carver c(ws);
@@ -174,6 +174,7 @@ struct StemWs {
     partial = c.take<float>((size_t)bn_bwd_partial_rows(rows, 64) * 2 * 64);
     slab = c.take<float>(stem_wgrad_slab_bytes(N, g.OH, g.OW) / sizeof(float));
     dwv = c.take<float>(64 * 256);
+    red = c.take<double>(2 * 64 * 64);
     total = c.cur;
   }
   size_t total;
@@ -188,7 +189,7 @@ int stem_fwd_core(StemWs<T>& s, const float* x, const float* w, const float* gam
   if ((rc = stage_one<T>(w, 64, 3, 49, true, s.wv, (T*)nullptr, s.table, st))) return rc;
   if ((rc = launch_stem_conv_fwd<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.img4, s.wv, s.x0, s.ssum, s.ssq, st))) return rc;
   if ((rc = bn_finalize(s.ssum, s.ssq, stem_conv_stat_rows(N, g.OH, g.OW), 64, (double)N * g.OH * g.OW, gamma, beta, eps,
-                        0.1f, nullptr, nullptr, s.coef, s.coef + 64, s.coef + 128, s.coef + 192, st))) return rc;
+                        0.1f, nullptr, nullptr, s.coef, s.coef + 64, s.coef + 128, s.coef + 192, s.red, st))) return rc;
   return stem_bn_relu_pool<T>(s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.pool, s.idx, st);
 }
 
@@ -215,7 +216,7 @@ int stem_bwd_op(const float* dy, const float* x, const float* w, const float* ga
   int nr = 0;
   if ((rc = bn_bwd_reduce<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, rows, 64, s.partial, &nr, st))) return rc;
   if ((rc = bn_bwd_finalize(s.partial, nr, 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
-                            dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, st))) return rc;
+                            dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, s.red, st))) return rc;
   if ((rc = bn_bwd_apply<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, s.coef + 256, s.coef + 320,
                             s.coef + 384, s.dx0, (T*)nullptr, rows, 64, st))) return rc;
   if ((rc = launch_stem_conv_wgrad<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.dx0, s.img4, s.slab, s.dwv, st))) return rc;

@@ -35,6 +35,9 @@ template <> struct Mma<float> {
 
 #define TAP_LDS_BYTES 256
 
+// 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
+__device__ uint4 g_zero_page[16];
+
 template <int BM, int BN, typename T> constexpr int conv_gemm_lds_bytes() {
   constexpr int ab = 2 * (BM + BN) * 128;
   constexpr int cpitch = BN * (int)sizeof(T) + 16;
@@ -100,39 +103,49 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
                              (size_t)(n0 + lr) * p.wrow * sizeof(T);
   const size_t w_pass = (size_t)32 * p.wrow * sizeof(T);
 
-  int tap = 0, c = jc * EPC;
-  while (c >= C) { c -= C; ++tap; }
+  int tap = (jc * EPC) / C, c = jc * EPC - tap * C;
   const int nk = ntaps * C / BK;
 
-  uint4 ra[AP], rb[BP];
-  auto load_tile = [&]() {
-    const int toff = s_tap[tap], tyx = s_tap[16 + tap], wk = s_tap[32 + tap] + c;
-    const int oy = (int)(short)(tyx & 0xffff), ox = tyx >> 16;
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int iy = a_iy[i] + oy, ix = a_ix[i] + ox;
-      bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (ok) ra[i] = *reinterpret_cast<const uint4*>(in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T));
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i)
-      rb[i] = *reinterpret_cast<const uint4*>(w_b + i * w_pass + (size_t)wk * sizeof(T));
-    c += BK;
-    while (c >= C) { c -= C; ++tap; }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      int row = lr + 32 * i;
-      *reinterpret_cast<uint4*>(As + buf * A_BYTES + row * 128 + ((jc ^ ((row >> 1) & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      int row = lr + 32 * i;
-      *reinterpret_cast<uint4*>(Bs + buf * B_BYTES + row * 128 + ((jc ^ ((row >> 1) & 7)) << 4)) = rb[i];
-    }
-  };
+  // Register-staged loads are written as macros over named scalars' arrays indexed by unrolled
+  // constants only: a by-reference lambda capture sent these arrays through scratch memory.
+  // Out-of-image taps read a global zero page instead of branching around the load.
+  // Staging registers are NAMED scalars (not arrays): hipcc kept `uint4 ra[AP]` in scratch memory,
+  // which put a vmcnt(0) + scratch store behind every global load.
+  static_assert(AP == 4 && (BP == 2 || BP == 4), "staging registers are written out for BM=128, BN=64/128");
+  u32x4_t ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_zero_page);
+
+#define LOAD_A(i, R)                                                                         \
+  {                                                                                          \
+    const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                          \
+    const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;              \
+    const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);      \
+    R = *reinterpret_cast<const u32x4_t*>(ok ? src : zero_page);                             \
+  }
+#define LOAD_B(i, R) R = *reinterpret_cast<const u32x4_t*>(w_b + (i) * w_pass + (size_t)wk * sizeof(T));
+#define LOAD_TILE()                                                                          \
+  do {                                                                                       \
+    const int toff = s_tap[tap], tyx = s_tap[16 + tap], wk = s_tap[32 + tap] + c;            \
+    const int oy = (int)(short)(tyx & 0xffff), ox = tyx >> 16;                               \
+    LOAD_A(0, ra0) LOAD_A(1, ra1) LOAD_A(2, ra2) LOAD_A(3, ra3)                              \
+    LOAD_B(0, rb0) LOAD_B(1, rb1)                                                            \
+    if constexpr (BP > 2) { LOAD_B(2, rb2) LOAD_B(3, rb3) }                                  \
+    c += BK;                                                                                 \
+    const int wrap = (c >= C ? 1 : 0) + (c >= 2 * C ? 1 : 0);                                \
+    c -= wrap * C;                                                                           \
+    tap += wrap;                                                                             \
+  } while (0)
+
+#define ST_ROW(base, bytes, buf, i, R)                                                       \
+  *reinterpret_cast<u32x4_t*>((base) + (buf) * (bytes) + (lr + 32 * (i)) * 128 +            \
+                              ((jc ^ (((lr + 32 * (i)) >> 1) & 7)) << 4)) = R;
+#define STORE_TILE(buf)                                                                      \
+  do {                                                                                       \
+    ST_ROW(As, A_BYTES, buf, 0, ra0) ST_ROW(As, A_BYTES, buf, 1, ra1)                        \
+    ST_ROW(As, A_BYTES, buf, 2, ra2) ST_ROW(As, A_BYTES, buf, 3, ra3)                        \
+    ST_ROW(Bs, B_BYTES, buf, 0, rb0) ST_ROW(Bs, B_BYTES, buf, 1, rb1)                        \
+    if constexpr (BP > 2) { ST_ROW(Bs, B_BYTES, buf, 2, rb2) ST_ROW(Bs, B_BYTES, buf, 3, rb3) } \
+  } while (0)
 
   const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wm = wid / WAVES_N, wn = wid - wm * WAVES_N;
@@ -143,16 +156,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) {
-    load_tile();
-    store_tile(0);
+    LOAD_TILE();
+    STORE_TILE(0);
   }
   __syncthreads();
+  const unsigned char* Ab0 = As + (wm * WM + l15) * 128;
+  const unsigned char* Bb0 = Bs + (wn * WN + l15) * 128;
+  const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile();
-    const unsigned char* Ab = As + cur * A_BYTES + (wm * WM + l15) * 128;
-    const unsigned char* Bb = Bs + cur * B_BYTES + (wn * WN + l15) * 128;
-    const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
+    const bool more = kt + 1 < nk;
+    if (more) LOAD_TILE();
+    const unsigned char* Ab = Ab0 + cur * A_BYTES;
+    const unsigned char* Bb = Bb0 + cur * B_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int off = ((4 * s + g) ^ sw) << 4;
@@ -166,9 +182,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
         for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    if (more) STORE_TILE(cur ^ 1);
     __syncthreads();
   }
+#undef LOAD_TILE
+#undef STORE_TILE
+#undef LOAD_A
+#undef LOAD_B
+#undef ST_ROW
 
   // ---- epilogue: acc -> LDS [pixel][channel] (packed) -> coalesced 16-byte stores
   unsigned char* Cs = smem + TAP_LDS_BYTES;

@@ -9,7 +9,12 @@
 int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, double count,
                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                 float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                hipStream_t st);
+                double* scratch, hipStream_t st);
+// scratch for the two finalize calls: 2 * 64 * C doubles (may be null: single-stage reduction)
+static inline size_t bn_reduce_scratch_bytes(int C) { return (size_t)2 * 64 * C * sizeof(double); }
+// in[nrows][cols] -> out[G][cols] (and in1 -> out[G..2G) when given)
+template <typename OUT>
+int partial_reduce(const float* in0, const float* in1, int nrows, int cols, int G, OUT* out, hipStream_t st);
 int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                    const float* running_var, float eps, float* scale, float* shift, hipStream_t st);
 // y = [relu](x*scale[c] + shift[c] [+ res | + res*rscale[c] + rshift[c]]);  rows*C elements
@@ -32,7 +37,7 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
 // -> dgamma, dbeta (may be null) and dx = cA*dz + cB*x + cC coefficient vectors
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, hipStream_t st);
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st);
 // dx = cA*dz + cB*x + cC ; optionally also writes dz (masked dy) to dz_out
 template <typename T>
 int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,

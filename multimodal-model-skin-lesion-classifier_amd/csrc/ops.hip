@@ -58,8 +58,60 @@ __device__ __forceinline__ void block_col_reduce(float (&acc)[NQ][EPC], int cx, 
   }
 }
 
+// ------------------------------------------------------------------ row-partial pre-reduction
+// in[nrows][cols] -> out[G][cols]: group g sums rows [g*per, (g+1)*per).  Conv epilogues / wgrad splits
+// leave up to ~25k partial rows; reducing them in one finalize block per 64 channels was latency-bound
+// (200 us per BatchNorm), so a wide first stage brings the row count down to <= 64 first.
+template <typename OUT>
+__global__ __launch_bounds__(512) void partial_reduce_kernel(const float* __restrict__ in0,
+                                                             const float* __restrict__ in1, int nrows, int cols,
+                                                             int G, OUT* __restrict__ out) {
+  __shared__ OUT red[8][64];
+  const float* in = blockIdx.z ? in1 : in0;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int per = (nrows + G - 1) / G;
+  const int r0 = blockIdx.y * per;
+  const int r1 = min(nrows, r0 + per);
+  OUT a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (c < cols) {
+    int r = r0 + ry;
+    for (; r + 24 < r1; r += 32) {
+      a0 += (OUT)in[(size_t)r * cols + c];
+      a1 += (OUT)in[(size_t)(r + 8) * cols + c];
+      a2 += (OUT)in[(size_t)(r + 16) * cols + c];
+      a3 += (OUT)in[(size_t)(r + 24) * cols + c];
+    }
+    for (; r < r1; r += 8) a0 += (OUT)in[(size_t)r * cols + c];
+  }
+  red[ry][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    OUT s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += red[i][cx];
+    out[((size_t)blockIdx.z * G + blockIdx.y) * cols + c] = s;
+  }
+}
+
+template <typename OUT>
+int partial_reduce(const float* in0, const float* in1, int nrows, int cols, int G, OUT* out, hipStream_t st) {
+  hipLaunchKernelGGL(partial_reduce_kernel<OUT>, dim3(ceil_div(cols, 64), G, in1 ? 2 : 1), dim3(512), 0, st, in0, in1,
+                     nrows, cols, G, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template int partial_reduce<float>(const float*, const float*, int, int, int, float*, hipStream_t);
+template int partial_reduce<double>(const float*, const float*, int, int, int, double*, hipStream_t);
+
+static inline int reduce_groups(int nrows) {
+  int g = (nrows + 31) / 32;
+  return g > 64 ? 64 : (g < 1 ? 1 : g);
+}
+
 // ------------------------------------------------------------------ BN forward
-__global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* __restrict__ ssq, int nrows,
+template <typename IN>
+__global__ void bn_finalize_kernel(const IN* __restrict__ ssum, const IN* __restrict__ ssq, int nrows,
                                    int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum,
                                    float* running_mean, float* running_var, float* scale, float* shift,
@@ -95,10 +147,19 @@ __global__ void bn_finalize_kernel(const float* __restrict__ ssum, const float* 
 int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, double count,
                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                 float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, stat_sum, stat_sq, nrows, C,
-                     count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
-                     save_invstd);
+                double* scratch, hipStream_t st) {
+  if (scratch && nrows > 64) {
+    const int G = reduce_groups(nrows);
+    int rc = partial_reduce<double>(stat_sum, stat_sq, nrows, C, G, scratch, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch,
+                       scratch + (size_t)G * C, G, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                       scale, shift, save_mean, save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, stat_sum, stat_sq, nrows,
+                       C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
+                       save_invstd);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -271,7 +332,8 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
   return MMSKIN_OK;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nrows, int C, double count,
+template <typename IN>
+__global__ void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                        float* cA, float* cB, float* cC) {
@@ -302,9 +364,17 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nr
 
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
-                     gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st) {
+  if (scratch && nrows > 64) {
+    const int G = reduce_groups(nrows);
+    int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -9,6 +9,7 @@
 // own fp32 slab (deterministic, no atomics) and wgrad_reduce sums the slabs straight into the
 // OIHW gradient tensor.
 #include "conv.h"
+#include "ops.h"
 
 template <typename T> struct WG;
 template <> struct WG<bf16_t> { static constexpr int MS = 32; };
@@ -24,6 +25,8 @@ template <typename T, int PITCH> __device__ __forceinline__ int wg_swz(int row) 
     return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
   }
 }
+
+__device__ uint4 g_wzero_page[16];  // zeros: source for rows past the split / padding taps
 
 __device__ __forceinline__ uint2 lds_read_tr16_b64(const unsigned char* p) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -76,42 +79,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const unsigned char* dy_b = reinterpret_cast<const unsigned char*>(p.dy);
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
 
-  uint4 rx[NX], ry[NY];
-  int m_stage = m_begin;  // first row of the stage the next load_stage() fetches
-  auto load_stage = [&]() {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      int m = m_stage + x_row[i];
-      rx[i] = make_uint4(0, 0, 0, 0);
-      if (m < m_end)
-        rx[i] = *reinterpret_cast<const uint4*>(dy_b + ((size_t)m * p.Cout + o0 + x_ch[i] * EPC) * sizeof(T));
-    }
-#pragma unroll
-    for (int i = 0; i < NY; ++i) {
-      int m = m_stage + y_row[i];
-      int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];
-      bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
-      ry[i] = make_uint4(0, 0, 0, 0);
-      if (ok)
-        ry[i] = *reinterpret_cast<const uint4*>(
-            in_b + ((int64_t)((y_img[i] * p.IH + iy) * p.IW + ix) * p.Cpitch + y_c[i]) * (int)sizeof(T));
-      // advance this row's pixel by MS for the next stage
-      y_ox[i] += MS;
-      while (y_ox[i] >= p.OW) {
-        y_ox[i] -= p.OW;
-        if (++y_oy[i] == p.OH) { y_oy[i] = 0; ++y_img[i]; }
-      }
-    }
-    m_stage += MS;
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i)
-      *reinterpret_cast<uint4*>(Xs + buf * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = rx[i];
-#pragma unroll
-    for (int i = 0; i < NY; ++i)
-      *reinterpret_cast<uint4*>(Ys + buf * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = ry[i];
-  };
+  // named staging registers (arrays of uint4 ended up in scratch memory)
+  static_assert(NX <= 2 && NY <= 2, "staging registers are written out for at most 2 chunks per thread");
+  u32x4_t rx0, rx1, ry0, ry1;
+  int m_stage = m_begin;  // first row of the stage the next LOAD_STAGE() fetches
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_wzero_page);
+  const int OWr = p.OW, OHr = p.OH;
+
+#define LOAD_X(i, R)                                                                                   \
+  {                                                                                                    \
+    const int m = m_stage + x_row[i];                                                                  \
+    const unsigned char* src = dy_b + ((size_t)m * p.Cout + o0 + x_ch[i] * EPC) * sizeof(T);           \
+    R = *reinterpret_cast<const u32x4_t*>(m < m_end ? src : zero_page);                                \
+  }
+#define LOAD_Y(i, R)                                                                                   \
+  {                                                                                                    \
+    const int m = m_stage + y_row[i];                                                                  \
+    const int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];                            \
+    const bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;       \
+    const unsigned char* src =                                                                         \
+        in_b + ((int64_t)((y_img[i] * p.IH + iy) * p.IW + ix) * p.Cpitch + y_c[i]) * (int)sizeof(T);   \
+    R = *reinterpret_cast<const u32x4_t*>(ok ? src : zero_page);                                       \
+    /* advance this row's pixel by MS for the next stage */                                            \
+    int nx = y_ox[i] + MS;                                                                             \
+    const int qy = nx / OWr;                                                                           \
+    nx -= qy * OWr;                                                                                    \
+    const int ny = y_oy[i] + qy;                                                                       \
+    const int qi = ny / OHr;                                                                           \
+    y_ox[i] = nx; y_oy[i] = ny - qi * OHr; y_img[i] += qi;                                             \
+  }
+#define LOAD_STAGE()                                                                                   \
+  do {                                                                                                 \
+    LOAD_X(0, rx0) if constexpr (NX > 1) LOAD_X(NX - 1, rx1)                                           \
+    LOAD_Y(0, ry0) if constexpr (NY > 1) LOAD_Y(NY - 1, ry1)                                           \
+    m_stage += MS;                                                                                     \
+  } while (0)
+#define ST_X(buf, i, R) *reinterpret_cast<u32x4_t*>(Xs + (buf) * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = R;
+#define ST_Y(buf, i, R) *reinterpret_cast<u32x4_t*>(Ys + (buf) * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = R;
+#define STORE_STAGE(buf)                                                                               \
+  do {                                                                                                 \
+    ST_X(buf, 0, rx0) if constexpr (NX > 1) ST_X(buf, NX - 1, rx1)                                     \
+    ST_Y(buf, 0, ry0) if constexpr (NY > 1) ST_Y(buf, NY - 1, ry1)                                     \
+  } while (0)
 
   const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   const int wo = wid >> 1, wk = wid & 1;  // wave position: cout half, k half
@@ -122,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     for (int j = 0; j < FO; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nstage = (m_end - m_begin + MS - 1) / MS;
-  if (nstage > 0) { load_stage(); store_stage(0); }
+  if (nstage > 0) { LOAD_STAGE(); STORE_STAGE(0); }
   __syncthreads();
   for (int s = 0; s < nstage; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nstage) load_stage();
+    if (s + 1 < nstage) LOAD_STAGE();
     const unsigned char* Xb = Xs + cur * X_BYTES;
     const unsigned char* Yb = Ys + cur * Y_BYTES;
     if constexpr (sizeof(T) == 2) {
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fx[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (s + 1 < nstage) store_stage(cur ^ 1);
+    if (s + 1 < nstage) STORE_STAGE(cur ^ 1);
     __syncthreads();
   }
 
@@ -222,11 +231,14 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
   nsplit = ceil_div(M, mps);
 }
 
+#define WG_DIRECT_SPLITS 32   // more splits than this are pre-reduced to WG_GROUPS partial slabs first
+#define WG_GROUPS 16
+
 template <typename T>
 static size_t slab_bytes(int M, int Cout, int Ktot) {
   int BO, BKK, ns, mps;
   wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps);
-  return (size_t)ns * Cout * Ktot * sizeof(float);
+  return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * Cout * Ktot * sizeof(float);
 }
 size_t conv_wgrad_slab_bytes(const ConvShape& s) {
   int M = s.N * s.OH() * s.OW(), K = s.kh * s.kw * s.Cin;
@@ -263,7 +275,15 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   size_t total = (size_t)a.Cout * a.Ktot;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a.slab, dw, a.nsplit, a.Cout,
+  const float* src = a.slab;
+  int nsrc = a.nsplit;
+  if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction
+    float* slab2 = a.slab + (size_t)a.nsplit * total;
+    if ((rc = partial_reduce<float>(a.slab, nullptr, a.nsplit, (int)total, WG_GROUPS, slab2, st))) return rc;
+    src = slab2;
+    nsrc = WG_GROUPS;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout,
                      C_for_layout, ntaps_for_layout);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
