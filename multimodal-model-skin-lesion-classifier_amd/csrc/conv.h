@@ -35,6 +35,7 @@ struct ConvGemmArgs {
   int Sy, Sx, OS;
   int OHf, OWf;
   int ncls, total_mblk, nblk_n;
+  int ablate;          // debug/timing only: bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores
   TapClass cls[4];
 };
 
@@ -52,6 +53,10 @@ struct WgradArgs {
   int nblk_o, nblk_k;  // tiles over Cout / Ktot
   int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
 };
+
+// pipelined production kernel (conv_pipe.hip); fills a.nblk_n
+template <typename T>
+int launch_conv_pipe(ConvGemmArgs& a, hipStream_t st);
 
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,

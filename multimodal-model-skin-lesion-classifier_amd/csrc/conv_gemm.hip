@@ -15,6 +15,9 @@
 // consecutive output channels of one pixel -> packed LDS-staged epilogue with full-line stores.
 // Optional epilogue: per-row-block BatchNorm partial sums (deterministic slab, no atomics), and an
 // addend tensor (residual / accumulation).
+#include <stdlib.h>
+#include <string.h>
+
 #include "conv.h"
 
 template <typename T> struct Mma;
@@ -103,48 +106,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
                              (size_t)(n0 + lr) * p.wrow * sizeof(T);
   const size_t w_pass = (size_t)32 * p.wrow * sizeof(T);
 
-  int tap = (jc * EPC) / C, c = jc * EPC - tap * C;
+  // LDS-DMA staging (global_load_lds_dwordx4): one wave-instruction lands 64 x 16 B = 8 tile rows
+  // contiguously in LDS (wave-uniform base + lane*16), so the bank swizzle is applied to the per-lane
+  // SOURCE chunk instead: LDS position jc of row r receives source chunk jc ^ ((r>>1)&7), and the
+  // fragment reads below apply the same XOR.  No staging VGPRs, no ds_write.
+  const int sc = jc ^ ((lr >> 1) & 7);            // source chunk this lane fetches (same for every pass)
+  int tap = (sc * EPC) / C, c = sc * EPC - tap * C;
   const int nk = ntaps * C / BK;
-
-  // Register-staged loads are written as macros over named scalars' arrays indexed by unrolled
-  // constants only: a by-reference lambda capture sent these arrays through scratch memory.
-  // Out-of-image taps read a global zero page instead of branching around the load.
-  // Staging registers are NAMED scalars (not arrays): hipcc kept `uint4 ra[AP]` in scratch memory,
-  // which put a vmcnt(0) + scratch store behind every global load.
-  static_assert(AP == 4 && (BP == 2 || BP == 4), "staging registers are written out for BM=128, BN=64/128");
-  u32x4_t ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_zero_page);
+  const int wid_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-#define LOAD_A(i, R)                                                                         \
-  {                                                                                          \
-    const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                          \
-    const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;              \
-    const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);      \
-    R = *reinterpret_cast<const u32x4_t*>(ok ? src : zero_page);                             \
-  }
-#define LOAD_B(i, R) R = *reinterpret_cast<const u32x4_t*>(w_b + (i) * w_pass + (size_t)wk * sizeof(T));
-#define LOAD_TILE()                                                                          \
+#define GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc), (lds_ptr_t)(ldst), 16, 0, 0)
+#define LOAD_TILE(buf)                                                                       \
   do {                                                                                       \
     const int toff = s_tap[tap], tyx = s_tap[16 + tap], wk = s_tap[32 + tap] + c;            \
     const int oy = (int)(short)(tyx & 0xffff), ox = tyx >> 16;                               \
-    LOAD_A(0, ra0) LOAD_A(1, ra1) LOAD_A(2, ra2) LOAD_A(3, ra3)                              \
-    LOAD_B(0, rb0) LOAD_B(1, rb1)                                                            \
-    if constexpr (BP > 2) { LOAD_B(2, rb2) LOAD_B(3, rb3) }                                  \
+    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                         \
+      const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                        \
+      const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;            \
+      const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);    \
+      GLDS16(ok ? src : zero_page, As + (buf) * A_BYTES + (32 * i + wid_u * 8) * 128);       \
+    }                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                           \
+      GLDS16(w_b + i * w_pass + (size_t)wk * sizeof(T), Bs + (buf) * B_BYTES + (32 * i + wid_u * 8) * 128); \
     c += BK;                                                                                 \
     const int wrap = (c >= C ? 1 : 0) + (c >= 2 * C ? 1 : 0);                                \
     c -= wrap * C;                                                                           \
     tap += wrap;                                                                             \
-  } while (0)
-
-#define ST_ROW(base, bytes, buf, i, R)                                                       \
-  *reinterpret_cast<u32x4_t*>((base) + (buf) * (bytes) + (lr + 32 * (i)) * 128 +            \
-                              ((jc ^ (((lr + 32 * (i)) >> 1) & 7)) << 4)) = R;
-#define STORE_TILE(buf)                                                                      \
-  do {                                                                                       \
-    ST_ROW(As, A_BYTES, buf, 0, ra0) ST_ROW(As, A_BYTES, buf, 1, ra1)                        \
-    ST_ROW(As, A_BYTES, buf, 2, ra2) ST_ROW(As, A_BYTES, buf, 3, ra3)                        \
-    ST_ROW(Bs, B_BYTES, buf, 0, rb0) ST_ROW(Bs, B_BYTES, buf, 1, rb1)                        \
-    if constexpr (BP > 2) { ST_ROW(Bs, B_BYTES, buf, 2, rb2) ST_ROW(Bs, B_BYTES, buf, 3, rb3) } \
   } while (0)
 
   const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -155,18 +145,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) {
-    LOAD_TILE();
-    STORE_TILE(0);
-  }
-  __syncthreads();
+  if (nk > 0) LOAD_TILE(0);
+  __syncthreads();   // (emits vmcnt(0): the LDS-DMA of tile 0 has landed for every wave)
   const unsigned char* Ab0 = As + (wm * WM + l15) * 128;
   const unsigned char* Bb0 = Bs + (wn * WN + l15) * 128;
   const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) LOAD_TILE();
+    if (kt + 1 < nk) LOAD_TILE(cur ^ 1);   // DMA of the next tile runs under this tile's MFMAs
     const unsigned char* Ab = Ab0 + cur * A_BYTES;
     const unsigned char* Bb = Bb0 + cur * B_BYTES;
 #pragma unroll
@@ -182,14 +168,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
         for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]);
     }
-    if (more) STORE_TILE(cur ^ 1);
     __syncthreads();
   }
 #undef LOAD_TILE
-#undef STORE_TILE
-#undef LOAD_A
-#undef LOAD_B
-#undef ST_ROW
+#undef GLDS16
 
   // ---- epilogue: acc -> LDS [pixel][channel] (packed) -> coalesced 16-byte stores
   unsigned char* Cs = smem + TAP_LDS_BYTES;
@@ -287,6 +269,14 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   for (int i = 0; i < a.ncls; ++i)
     ARG_CHECK((a.cls[i].ntaps * a.C) % DT<T>::BK == 0, "conv_gemm: K=%d not a multiple of %d",
               a.cls[i].ntaps * a.C, DT<T>::BK);
+  // MMSKIN_CONV_VARIANT=pipe selects the 8-wave / 3-stage kernel of conv_pipe.hip (A/B timing: it is
+  // ~15 % slower than this file's 4-wave, 2 workgroups-per-CU kernel on every ResNet-50 layer shape --
+  // profiles/r01_c_conv_ablation.txt); the default is the kernel of this file.
+  const char* var = getenv("MMSKIN_CONV_VARIANT");
+  const bool simple = !(var && !strcmp(var, "pipe"));
+  const char* abl = getenv("MMSKIN_CONV_ABLATE");   // timing experiments only
+  a.ablate = abl ? atoi(abl) : 0;
+  if (!simple) return launch_conv_pipe<T>(a, st);
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
     return launch_cfg<T, CONV_BM, 128, 2, 2>(a, st);

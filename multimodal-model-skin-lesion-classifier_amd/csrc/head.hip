@@ -10,75 +10,78 @@
 
 // ------------------------------------------------------------------ generic strided f32 GEMM
 // C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]) ; A(m,k) = a[m*sam + k*sak] ; B(n,k) = b[n*sbn + k*sbk]
-#define LG_PITCH 80
+// The head's GEMMs have M = batch (256) and N, K <= 2048: tiny for a 256-CU chip, so the kernel is built
+// for latency, not throughput: 32x32 output tiles (many workgroups), K-steps of 32 with the next step's
+// operands prefetched into registers while the current one is multiplied on the exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32, one 16x16 fragment per wave).
+#define LG_BK 32
+#define LG_T 32
+#define LG_PK 36   // pitch of a [row][k] tile (k-contiguous source)
+#define LG_PM 48   // pitch of a [k][row] tile (row-contiguous source)
+template <bool KC> __device__ __forceinline__ int lg_idx(int row, int k) { return KC ? row * LG_PK + k : k * LG_PM + row; }
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ c, const float* __restrict__ bias, int M,
                                                        int N, int K, int64_t sam, int64_t sak, int64_t sbn,
                                                        int64_t sbk, int64_t ldc, int relu) {
-  __shared__ float As[16 * LG_PITCH];
-  __shared__ float Bs[16 * LG_PITCH];
+  __shared__ float As[LG_BK * LG_PM];
+  __shared__ float Bs[LG_BK * LG_PM];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * LG_T, n0 = blockIdx.x * LG_T;
   const int wm = wid >> 1, wn = wid & 1;
-  f32x4_t acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float ra[4], rb[4];
+  // element e = tid + 256*i of a 32x32 tile: k-contiguous sources walk k fastest, else rows fastest
+  auto coords = [&](bool kc, int e, int& row, int& kk) { if (kc) { row = e >> 5; kk = e & 31; } else { row = e & 31; kk = e >> 5; } };
+#define LG_FETCH(k0)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+    int row, kk;                                                                                        \
+    coords(A_KC, tid + 256 * i, row, kk);                                                               \
+    ra[i] = (m0 + row < M && (k0) + kk < K) ? a[(int64_t)(m0 + row) * sam + (int64_t)((k0) + kk) * sak] : 0.f; \
+    coords(B_KC, tid + 256 * i, row, kk);                                                               \
+    rb[i] = (n0 + row < N && (k0) + kk < K) ? b[(int64_t)(n0 + row) * sbn + (int64_t)((k0) + kk) * sbk] : 0.f; \
+  }
+  LG_FETCH(0)
+  for (int k0 = 0; k0 < K; k0 += LG_BK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int e = tid + 256 * i;
       int row, kk;
-      if (A_KC) { row = e >> 4; kk = e & 15; } else { row = e & 63; kk = e >> 6; }
-      float v = 0.f;
-      if (m0 + row < M && k0 + kk < K) v = a[(int64_t)(m0 + row) * sam + (int64_t)(k0 + kk) * sak];
-      As[kk * LG_PITCH + row] = v;
-      if (B_KC) { row = e >> 4; kk = e & 15; } else { row = e & 63; kk = e >> 6; }
-      v = 0.f;
-      if (n0 + row < N && k0 + kk < K) v = b[(int64_t)(n0 + row) * sbn + (int64_t)(k0 + kk) * sbk];
-      Bs[kk * LG_PITCH + row] = v;
+      coords(A_KC, tid + 256 * i, row, kk);
+      As[lg_idx<A_KC>(row, kk)] = ra[i];
+      coords(B_KC, tid + 256 * i, row, kk);
+      Bs[lg_idx<B_KC>(row, kk)] = rb[i];
     }
     __syncthreads();
+    if (k0 + LG_BK < K) { LG_FETCH(k0 + LG_BK) }   // in flight while this step is multiplied
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float fa[2], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fa[j] = As[(4 * s + g) * LG_PITCH + wm * 32 + j * 16 + l15];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fb[i] = Bs[(4 * s + g) * LG_PITCH + wn * 32 + i * 16 + l15];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    for (int s = 0; s < LG_BK / 4; ++s) {
+      float fa = As[lg_idx<A_KC>(wm * 16 + l15, 4 * s + g)];
+      float fb = Bs[lg_idx<B_KC>(wn * 16 + l15, 4 * s + g)];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fb, fa, acc, 0, 0, 0);
     }
     __syncthreads();
   }
+#undef LG_FETCH
   // D[i = n][j = m]: lane holds m = l15, n = 4g + reg
+  const int m = m0 + wm * 16 + l15;
+  if (m < M) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int m = m0 + wm * 32 + j * 16 + l15;
-      if (m >= M) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int n = n0 + wn * 32 + i * 16 + 4 * g + r;
-        if (n < N) {
-          float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
-          if (relu) v = fmaxf(v, 0.f);
-          c[(int64_t)m * ldc + n] = v;
-        }
+    for (int r = 0; r < 4; ++r) {
+      int n = n0 + wn * 16 + 4 * g + r;
+      if (n < N) {
+        float v = acc[r] + (bias ? bias[n] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        c[(int64_t)m * ldc + n] = v;
       }
     }
+  }
 }
 
 static int gemm_f32(const float* a, const float* b, float* c, const float* bias, int M, int N, int K, int64_t sam,
                     int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int relu, hipStream_t st) {
   if (M <= 0 || N <= 0) return MMSKIN_OK;
-  dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+  dim3 grid(ceil_div(N, LG_T), ceil_div(M, LG_T));
   const bool akc = sak == 1, bkc = sbk == 1;
 #define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, c, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu)
   if (akc && bkc) LAUNCH(true, true);
@@ -94,12 +97,20 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __re
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
-__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) {
-    float s = 0.f;
-    for (int m = 0; m < M; ++m) s += x[(int64_t)m * N + n];
-    out[n] = s;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;     // 32 columns x 8 row lanes per block
+  const int n = blockIdx.x * 32 + cx;
+  float s = 0.f;
+  if (n < N)
+    for (int m = ry; m < M; m += 8) s += x[(int64_t)m * N + n];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][cx];
+    out[n] = t;
   }
 }
 static inline int grid1d(int64_t n) {
@@ -493,7 +504,7 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     if ((rc = gemm_f32(g, x, dw, nullptr, N, K, M, 1, N, 1, K, K, 0, st))) return rc;
   }
   if (db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, g, db, M, N);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, g, db, M, N);
     HIP_CHECK_RET(hipGetLastError());
   }
   return MMSKIN_OK;

@@ -94,8 +94,49 @@ __global__ __launch_bounds__(512) void partial_reduce_kernel(const float* __rest
   }
 }
 
+// float4 variant for wide matrices (wgrad split slabs): 64 threads cover 256 columns, 8 row lanes
+__global__ __launch_bounds__(512) void partial_reduce4_kernel(const float* __restrict__ in, int nrows, int cols,
+                                                              int G, float* __restrict__ out) {
+  __shared__ float4 red[8][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cx) * 4;
+  const int per = (nrows + G - 1) / G;
+  const int r0 = blockIdx.y * per;
+  const int r1 = min(nrows, r0 + per);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  if (c < cols) {
+    int r = r0 + ry;
+    for (; r + 8 < r1; r += 16) {
+      float4 u = *reinterpret_cast<const float4*>(in + (size_t)r * cols + c);
+      float4 v = *reinterpret_cast<const float4*>(in + (size_t)(r + 8) * cols + c);
+      a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+      a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    }
+    for (; r < r1; r += 8) {
+      float4 u = *reinterpret_cast<const float4*>(in + (size_t)r * cols + c);
+      a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+    }
+  }
+  red[ry][cx] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    float4 s = red[0][cx];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s.x += red[i][cx].x; s.y += red[i][cx].y; s.z += red[i][cx].z; s.w += red[i][cx].w; }
+    *reinterpret_cast<float4*>(out + (size_t)blockIdx.y * cols + c) = s;
+  }
+}
+
 template <typename OUT>
 int partial_reduce(const float* in0, const float* in1, int nrows, int cols, int G, OUT* out, hipStream_t st) {
+  if constexpr (sizeof(OUT) == 4) {
+    if (!in1 && cols % 4 == 0) {
+      hipLaunchKernelGGL(partial_reduce4_kernel, dim3(ceil_div(cols, 256), G), dim3(512), 0, st, in0, nrows, cols, G,
+                         reinterpret_cast<float*>(out));
+      HIP_CHECK_RET(hipGetLastError());
+      return MMSKIN_OK;
+    }
+  }
   hipLaunchKernelGGL(partial_reduce_kernel<OUT>, dim3(ceil_div(cols, 64), G, in1 ? 2 : 1), dim3(512), 0, st, in0, in1,
                      nrows, cols, G, out);
   HIP_CHECK_RET(hipGetLastError());

@@ -34,9 +34,12 @@ __device__ __forceinline__ uint2 lds_read_tr16_b64(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int BO, int BKK>
+// MSF scales the rows staged per barrier: small output tiles stage more pixel rows per step so every
+// barrier-to-barrier interval carries >= 16 MFMAs per wave and 16-32 KB of loads (a 64x64 tile with 32
+// rows per step was latency-bound at 48 TF/s).
+template <typename T, int BO, int BKK, int MSF>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
-  constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS;
+  constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS * MSF;
   constexpr int PX = BO * (int)sizeof(T), PY = BKK * (int)sizeof(T);
   constexpr int X_BYTES = MS * PX, Y_BYTES = MS * PY;
   constexpr int CPR_X = BO / EPC, CPR_Y = BKK / EPC;  // chunks per row
@@ -80,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
 
   // named staging registers (arrays of uint4 ended up in scratch memory)
-  static_assert(NX <= 2 && NY <= 2, "staging registers are written out for at most 2 chunks per thread");
-  u32x4_t rx0, rx1, ry0, ry1;
+  static_assert(NX <= 4 && NY <= 4 && NX != 3 && NY != 3, "staging registers are written out for 1, 2 or 4 chunks per thread");
+  u32x4_t rx0, rx1, rx2, rx3, ry0, ry1, ry2, ry3;
   int m_stage = m_begin;  // first row of the stage the next LOAD_STAGE() fetches
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_wzero_page);
   const int OWr = p.OW, OHr = p.OH;
@@ -110,16 +113,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   }
 #define LOAD_STAGE()                                                                                   \
   do {                                                                                                 \
-    LOAD_X(0, rx0) if constexpr (NX > 1) LOAD_X(NX - 1, rx1)                                           \
-    LOAD_Y(0, ry0) if constexpr (NY > 1) LOAD_Y(NY - 1, ry1)                                           \
+    LOAD_X(0, rx0) if constexpr (NX > 1) LOAD_X(1 % NX, rx1)                                           \
+    if constexpr (NX > 2) { LOAD_X(2 % NX, rx2) LOAD_X(3 % NX, rx3) }                                  \
+    LOAD_Y(0, ry0) if constexpr (NY > 1) LOAD_Y(1 % NY, ry1)                                           \
+    if constexpr (NY > 2) { LOAD_Y(2 % NY, ry2) LOAD_Y(3 % NY, ry3) }                                  \
     m_stage += MS;                                                                                     \
   } while (0)
 #define ST_X(buf, i, R) *reinterpret_cast<u32x4_t*>(Xs + (buf) * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = R;
 #define ST_Y(buf, i, R) *reinterpret_cast<u32x4_t*>(Ys + (buf) * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = R;
 #define STORE_STAGE(buf)                                                                               \
   do {                                                                                                 \
-    ST_X(buf, 0, rx0) if constexpr (NX > 1) ST_X(buf, NX - 1, rx1)                                     \
-    ST_Y(buf, 0, ry0) if constexpr (NY > 1) ST_Y(buf, NY - 1, ry1)                                     \
+    ST_X(buf, 0, rx0) if constexpr (NX > 1) ST_X(buf, 1 % NX, rx1)                                     \
+    if constexpr (NX > 2) { ST_X(buf, 2 % NX, rx2) ST_X(buf, 3 % NX, rx3) }                            \
+    ST_Y(buf, 0, ry0) if constexpr (NY > 1) ST_Y(buf, 1 % NY, ry1)                                     \
+    if constexpr (NY > 2) { ST_Y(buf, 2 % NY, ry2) ST_Y(buf, 3 % NY, ry3) }                            \
   } while (0)
 
   const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
@@ -142,29 +149,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
       // transposing reads: lane (q,pp) of a 16-lane group addresses row q, columns 4pp..4pp+3 of a
       // 4x16 block; lane i receives column i of the 4 rows.  Two reads give k = 8g .. 8g+7.
       const int q = l15 >> 2, pp = l15 & 3;
-      uint4 fx[FO], fy[FK];
 #pragma unroll
-      for (int j = 0; j < FO; ++j) {
-        int colb = (wo * (BO / 2) + j * 16 + 4 * pp) * 2;  // byte offset in row
-        int r0 = 8 * g + q, r1 = r0 + 4;
-        uint2 lo = lds_read_tr16_b64(Xb + r0 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r0)) << 4) + (colb & 15));
-        uint2 hi = lds_read_tr16_b64(Xb + r1 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r1)) << 4) + (colb & 15));
-        fx[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      for (int ks = 0; ks < MS / 32; ++ks) {
+        uint4 fx[FO], fy[FK];
+        const int r0 = 32 * ks + 8 * g + q, r1 = r0 + 4;
+#pragma unroll
+        for (int j = 0; j < FO; ++j) {
+          int colb = (wo * (BO / 2) + j * 16 + 4 * pp) * 2;  // byte offset in row
+          uint2 lo = lds_read_tr16_b64(Xb + r0 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r0)) << 4) + (colb & 15));
+          uint2 hi = lds_read_tr16_b64(Xb + r1 * PX + (((colb >> 4) ^ wg_swz<T, PX>(r1)) << 4) + (colb & 15));
+          fx[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int i = 0; i < FK; ++i) {
+          int colb = (wk * (BKK / 2) + i * 16 + 4 * pp) * 2;
+          uint2 lo = lds_read_tr16_b64(Yb + r0 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r0)) << 4) + (colb & 15));
+          uint2 hi = lds_read_tr16_b64(Yb + r1 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r1)) << 4) + (colb & 15));
+          fy[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int i = 0; i < FK; ++i)
+#pragma unroll
+          for (int j = 0; j < FO; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fy[i]),
+                                                                __builtin_bit_cast(bf16x8_t, fx[j]), acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < FK; ++i) {
-        int colb = (wk * (BKK / 2) + i * 16 + 4 * pp) * 2;
-        int r0 = 8 * g + q, r1 = r0 + 4;
-        uint2 lo = lds_read_tr16_b64(Yb + r0 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r0)) << 4) + (colb & 15));
-        uint2 hi = lds_read_tr16_b64(Yb + r1 * PY + (((colb >> 4) ^ wg_swz<T, PY>(r1)) << 4) + (colb & 15));
-        fy[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      }
-#pragma unroll
-      for (int i = 0; i < FK; ++i)
-#pragma unroll
-        for (int j = 0; j < FO; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fy[i]),
-                                                              __builtin_bit_cast(bf16x8_t, fx[j]), acc[i][j], 0, 0, 0);
     } else {
 #pragma unroll
       for (int ks = 0; ks < MS / 4; ++ks) {
@@ -222,6 +231,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps) {
   BO = (Cout % 128 == 0) ? 128 : 64;
   BKK = (Ktot % 128 == 0) ? 128 : 64;
+  MS *= (BO + BKK == 128) ? 4 : (BO + BKK == 192 ? 2 : 1);   // rows per stage (MSF of the kernel)
   int tiles = (Cout / BO) * (Ktot / BKK);
   int want = ceil_div(1536, tiles);
   int max_split = M / (MS * 4) > 0 ? M / (MS * 4) : 1;
@@ -250,12 +260,12 @@ size_t stem_wgrad_slab_bytes(int N, int OH, int OW) {
   return a > b ? a : b;
 }
 
-template <typename T, int BO, int BKK>
+template <typename T, int BO, int BKK, int MSF>
 static int launch_wg(WgradArgs& a, hipStream_t st) {
   a.nblk_o = a.Cout / BO;
   a.nblk_k = a.Ktot / BKK;
   int grid = a.nblk_o * a.nblk_k * a.nsplit;
-  hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF>), dim3(grid), dim3(256), 0, st, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -267,10 +277,10 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   int BO, BKK;
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
   int rc;
-  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128>(a, st);
-  else if (BO == 128) rc = launch_wg<T, 128, 64>(a, st);
-  else if (BKK == 128) rc = launch_wg<T, 64, 128>(a, st);
-  else rc = launch_wg<T, 64, 64>(a, st);
+  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 1>(a, st);
+  else if (BO == 128) rc = launch_wg<T, 128, 64, 2>(a, st);
+  else if (BKK == 128) rc = launch_wg<T, 64, 128, 2>(a, st);
+  else rc = launch_wg<T, 64, 64, 4>(a, st);
   if (rc) return rc;
   size_t total = (size_t)a.Cout * a.Ktot;
   int blocks = (int)((total + 255) / 256);

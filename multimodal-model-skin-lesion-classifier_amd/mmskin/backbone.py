@@ -104,10 +104,18 @@ class _BackboneFn(torch.autograd.Function):
         call("mmskin_backbone_backward", plan.handle, ptr(dfeat), ptr(module._flat_p), ptr(plan.workspace), ptr(grads),
              stream())
         module.last_flat_grad = grads
-        out = [None, None, None]
-        for need, (off, numel, shape) in zip(ctx.needs_input_grad[3:], module._layout):
-            out.append(grads[off:off + numel].view(shape) if need else None)
-        return tuple(out)
+        # Hand every parameter its gradient as a VIEW of the flat buffer (what DDP calls
+        # gradient_as_bucket_view): no per-parameter copy, and the data-parallel all-reduce can run on
+        # the one flat buffer.  Autograd itself gets None for these inputs.
+        for need, p, (off, numel, shape) in zip(ctx.needs_input_grad[3:], module.parameters(), module._layout):
+            if not need:
+                continue
+            view = grads[off:off + numel].view(shape)
+            if p.grad is None:
+                p.grad = view
+            else:
+                p.grad.add_(view)
+        return (None, None, None) + (None,) * len(module._layout)
 
 
 class HipResNet(nn.Module):
