@@ -115,21 +115,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const int nk = ntaps * C / BK;
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_zero_page);
   const int wid_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
+  const int abl = p.ablate;                                     // timing experiments only (0 in production)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-#define GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gsrc), (lds_ptr_t)(ldst), 16, 0, 0)
+// The DMA is issued from inline asm: through the builtin, hipcc models it as an LDS store that may alias
+// every ds_read and drains s_waitcnt vmcnt(0) in front of the MFMA loop, which serialised load and
+// compute (ablation in profiles/r01_c_conv_ablation.txt: 35 us loads + 35 us MFMA = 61 us, no overlap).
+// M0 = wave-uniform LDS byte offset; one wait state between the M0 write and the DMA.
+#define GLDS16(gsrc, ldst)                                                                                \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"((uint32_t)(uintptr_t)(lds_ptr_t)(ldst)), \
+               "v"((const void*)(gsrc)) : "memory")
 #define LOAD_TILE(buf)                                                                       \
   do {                                                                                       \
     const int toff = s_tap[tap], tyx = s_tap[16 + tap], wk = s_tap[32 + tap] + c;            \
     const int oy = (int)(short)(tyx & 0xffff), ox = tyx >> 16;                               \
-    _Pragma("unroll") for (int i = 0; i < AP; ++i) {                                         \
+    if (!(abl & 1)) _Pragma("unroll") for (int i = 0; i < AP; ++i) {                         \
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                        \
       const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;            \
       const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);    \
       GLDS16(ok ? src : zero_page, As + (buf) * A_BYTES + (32 * i + wid_u * 8) * 128);       \
     }                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < BP; ++i)                                           \
+    if (!(abl & 2)) _Pragma("unroll") for (int i = 0; i < BP; ++i)                           \
       GLDS16(w_b + i * w_pass + (size_t)wk * sizeof(T), Bs + (buf) * B_BYTES + (32 * i + wid_u * 8) * 128); \
     c += BK;                                                                                 \
     const int wrap = (c >= C ? 1 : 0) + (c >= 2 * C ? 1 : 0);                                \
@@ -146,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   if (nk > 0) LOAD_TILE(0);
-  __syncthreads();   // (emits vmcnt(0): the LDS-DMA of tile 0 has landed for every wave)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of tile 0 has landed ...
+  __syncthreads();                                   // ... and so has everybody else's
   const unsigned char* Ab0 = As + (wm * WM + l15) * 128;
   const unsigned char* Bb0 = Bs + (wn * WN + l15) * 128;
   const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     if (kt + 1 < nk) LOAD_TILE(cur ^ 1);   // DMA of the next tile runs under this tile's MFMAs
     const unsigned char* Ab = Ab0 + cur * A_BYTES;
     const unsigned char* Bb = Bb0 + cur * B_BYTES;
+    if (!(abl & 4))
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int off = ((4 * s + g) ^ sw) << 4;
@@ -168,11 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
         for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (it flew under the MFMAs above)
     __syncthreads();
   }
 #undef LOAD_TILE
 #undef GLDS16
 
+  if (abl & 16) return;   // timing experiments only
   // ---- epilogue: acc -> LDS [pixel][channel] (packed) -> coalesced 16-byte stores
   unsigned char* Cs = smem + TAP_LDS_BYTES;
 #pragma unroll
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
-    v.store(out_b + goff);
+    if (!(abl & 8)) v.store(out_b + goff);
   }
   if (p.stat_sum) {
     float* red = reinterpret_cast<float*>(Cs + BM * CPITCH);  // [2][ROWS_PER_PASS][BN]
