@@ -79,7 +79,7 @@ struct Plan {
   // workspace layout (bytes)
   size_t ws_bytes = 0;
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[6], off_slab, off_partial,
-      off_coefbwd, off_dwv, off_red;
+      off_coefbwd, off_dwv, off_red, off_partial_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
   size_t esz() const { return dtype == 1 ? 2 : 4; }
 };
@@ -196,6 +196,9 @@ int build_plan(Plan& p) {
     if (!u.stem) { size_t sb = conv_wgrad_slab_bytes(u.s); if (sb > slab_max) slab_max = sb; }
     size_t pr = (size_t)bn_bwd_partial_rows(rows, u.s.Cout) * 2 * u.s.Cout * sizeof(float);
     if (pr > partial_max) partial_max = pr;
+    // partial rows written by a dgrad epilogue that produces this unit's output-shaped gradient
+    pr = ((rows + 127) / 128 + 4) * 2 * u.s.Cout * sizeof(float);
+    if (pr > partial_max) partial_max = pr;
     if (u.s.Cout > maxC) maxC = u.s.Cout;
   }
   p.stat_bytes = stat_rows_max * sizeof(float);
@@ -220,6 +223,7 @@ int build_plan(Plan& p) {
   for (int i = 0; i < 6; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
   p.off_slab = carve(cur, slab_max);
   p.off_partial = carve(cur, partial_max);
+  p.off_partial_b = carve(cur, partial_max);
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
@@ -356,11 +360,30 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     return bn_bwd_apply<T>(dy, x, ymask, coef, coef + C, mode, cA, cB, cC, dx, dz, u.rows(), C, st);
   };
 
+  float* partial_b = reinterpret_cast<float*>(ws + p.off_partial_b);
+  // BN backward of unit u when `dz` is ALREADY masked and its partial sums (sum dz, sum dz*x) were
+  // produced by the epilogue of the dgrad launch that wrote dz: finalize + one apply pass.
+  auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx) -> int {
+    const int C = u.s.Cout;
+    float* coef = reinterpret_cast<float*>(ws + u.coef_off);
+    const T* x = reinterpret_cast<const T*>(ws + u.x_off);
+    float* cB = cA + C; float* cC = cA + 2 * C;
+    int r;
+    p.prof.begin(K_BN_BWD, st);
+    struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
+    if (p.prof.on) p.prof.bytes[K_BN_BWD] += 3.0 * u.rows() * C * sizeof(T);
+    if ((r = bn_bwd_finalize(part, nrows, C, (double)u.rows(), params + u.g_off, coef + 2 * C, coef + 3 * C,
+                             grads + u.g_off, grads + u.b_off, cA, cB, cC, reinterpret_cast<double*>(ws + p.off_red), st))) return r;
+    return bn_bwd_apply<T>(dz, x, nullptr, coef, coef + C, MASK_NONE, cA, cB, cC, dx, nullptr, u.rows(), C, st);
+  };
+
   Unit& last = p.units[p.blocks.back().units.back()];
   T* g = S[0];
   T* gin = S[1];
   if ((rc = avgpool_bwd<T>(dfeat, p.N, last.s.OH() * last.s.OW(), last.s.Cout, g, st))) return rc;
 
+  bool fused_ready = false;   // g already holds the masked dz of this block's final unit, partials in the slabs
+  int fused_rows = 0;
   for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
     Block& b = p.blocks[bi];
     const int nu = (int)b.units.size();
@@ -372,26 +395,52 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     T* dZ = S[4];
     T* dXd = S[5];
     const bool has_ds = b.ds >= 0;
-    if ((rc = bn_backward(ul, g, out, MASK_FROM_Y, dX, has_ds ? nullptr : dZ))) return rc;
-    if (has_ds)
-      if ((rc = bn_backward(p.units[b.ds], g, out, MASK_FROM_Y, dXd, nullptr))) return rc;
+    const T* dz_final;   // masked gradient of the block output (residual branch addend)
+    if (fused_ready) {
+      if ((rc = bn_backward_fused(ul, g, partial, fused_rows, dX))) return rc;
+      if (has_ds)
+        if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd))) return rc;
+      dz_final = g;
+    } else {
+      if ((rc = bn_backward(ul, g, out, MASK_FROM_Y, dX, has_ds ? nullptr : dZ))) return rc;
+      if (has_ds)
+        if ((rc = bn_backward(p.units[b.ds], g, out, MASK_FROM_Y, dXd, nullptr))) return rc;
+      dz_final = dZ;
+    }
     for (int i = nu - 1; i >= 0; --i) {
       Unit& u = p.units[b.units[i]];
       const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
       PROF(K_WGRAD, conv_flops(u.s), 0.0, launch_conv_wgrad<T>(u.s, dX, uin, slab, grads + u.w_off, st));
       if (i > 0) {
+        // dgrad writes the gradient of unit i-1's ReLU output; its epilogue applies that ReLU's mask and
+        // accumulates unit i-1's BN-backward sums, so the stand-alone reduce pass is gone.
         Unit& up = p.units[b.units[i - 1]];
-        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st));
-        if ((rc = bn_backward(up, dY, nullptr, MASK_FROM_X, dX, nullptr))) return rc;
+        float* cup = reinterpret_cast<float*>(ws + up.coef_off);
+        DgradFuse f;
+        f.x = ws + up.x_off; f.scale = cup; f.shift = cup + up.s.Cout; f.partial = partial;
+        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st, &f));
+        if ((rc = bn_backward_fused(up, dY, partial, f.rows_written, dX))) return rc;
       } else {
-        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0,
-             launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, has_ds ? (const T*)nullptr : dZ, st));
+        const T* addend = dz_final;
+        if (has_ds) {
+          Unit& d = p.units[b.ds];
+          PROF(K_WGRAD, conv_flops(d.s), 0.0, launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st));
+          PROF(K_CONV_DGRAD, conv_flops(d.s), 0.0, launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
+          addend = gin;   // main-branch dgrad accumulates on top, in place
+        }
+        DgradFuse f;
+        DgradFuse* fp = nullptr;
+        if (bi > 0) {   // gin is the gradient of the previous block's output: fuse that block's final BN reduce
+          Block& pb = p.blocks[bi - 1];
+          Unit& pu = p.units[pb.units.back()];
+          f.mask_y = ws + pu.y_off; f.x = ws + pu.x_off; f.partial = partial;
+          if (pb.ds >= 0) { f.x2 = ws + p.units[pb.ds].x_off; f.partial_b = partial_b; }
+          fp = &f;
+        }
+        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, addend, st, fp));
+        fused_ready = fp != nullptr;
+        fused_rows = f.rows_written;
       }
-    }
-    if (has_ds) {
-      Unit& d = p.units[b.ds];
-      PROF(K_WGRAD, conv_flops(d.s), 0.0, launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st));
-      PROF(K_CONV_DGRAD, conv_flops(d.s), 0.0, launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, gin, st));
     }
     T* t = g; g = gin; gin = t;
   }

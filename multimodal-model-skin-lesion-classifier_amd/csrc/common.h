@@ -65,6 +65,9 @@ template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
   float v[4];
+  __device__ __forceinline__ void from_raw(const u32x4_t& t) {
+    v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]); v[2] = __uint_as_float(t[2]); v[3] = __uint_as_float(t[3]);
+  }
   __device__ __forceinline__ void load(const void* p) {
     float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -75,6 +78,13 @@ template <> struct Chunk<float> {
 };
 template <> struct Chunk<bf16_t> {
   float v[8];
+  __device__ __forceinline__ void from_raw(const u32x4_t& t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(t[i] << 16);
+      v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+    }
+  }
   __device__ __forceinline__ void load(const void* p) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
     uint32_t w[4] = {t.x, t.y, t.z, t.w};

@@ -28,8 +28,18 @@ struct ConvGemmArgs {
   const void* w;       // staged weights [Cout][wtaps][C]   (K contiguous)
   void* out;           // [N][OHf][OWf][Cout]
   const void* addend;  // optional, same layout as out: out = acc + addend (may alias out)
-  float* stat_sum;     // optional per-row-block partial column sums   [total_mblk][Cout]
-  float* stat_sq;      // optional per-row-block partial column sum-sq [total_mblk][Cout]
+  float* stat_sum;     // optional per-row-block partial column sums   [total_mblk][stat_stride]
+  float* stat_sq;      // optional per-row-block partial: sum v*v, or sum v*ep_x when ep_x is set
+  // ---- fused BatchNorm-backward prologue of the CONSUMER of `out` (dgrad launches only):
+  // v = acc + addend; v *= mask; out = v; stat_sum += v; stat_sq += v*ep_x; stat_b_sq += v*ep_x2
+  const void* ep_mask_y;   // mask = (ep_mask_y > 0)      (ReLU after a residual add: mask from the block output)
+  const void* ep_x;        // raw BN input x of the consumer unit (same shape as out)
+  const float* ep_scale;   // with ep_shift: mask = (ep_x*scale + shift > 0)   (plain BN+ReLU)
+  const float* ep_shift;
+  const void* ep_x2;       // second raw tensor (downsample BN of the same block) -> stat_b_*
+  float* stat_b_sum;       // = sum v   (again, so the downsample finalize sees the same slab layout)
+  float* stat_b_sq;        // = sum v*ep_x2
+  int stat_stride;         // floats per partial row (Cout for forward stats, 2*Cout for the bwd layout)
   int N, IH, IW, C, Cpitch;
   int Cout, wrow;      // wrow = wtaps*C = elements per weight row
   int Sy, Sx, OS;
@@ -64,12 +74,26 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
 // number of stat partial rows the forward launch produces (rows of stat_sum / stat_sq)
 int conv_fwd_stat_rows(const ConvShape& s);
 
+// Optional epilogue fusion for launch_conv_dgrad (see ConvGemmArgs::ep_*): partial slabs use the
+// bn_bwd layout [row][2][C]; rows = conv_dgrad_partial_rows(s).
+struct DgradFuse {
+  const void* mask_y = nullptr;
+  const void* x = nullptr;
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  const void* x2 = nullptr;
+  float* partial = nullptr;     // [rows][2][Cin]: sum dz, sum dz*x
+  float* partial_b = nullptr;   // [rows][2][Cin]: sum dz, sum dz*x2
+  int rows_written = 0;         // out: partial rows the launch produced
+};
+int conv_dgrad_partial_rows(const ConvShape& s);
+
 // din[N][H][W][Cin] = dgrad(dout[N][OH][OW][Cout]); wt_staged is [Cin][kh*kw][Cout].
 // addend (optional, may alias din) is added in the epilogue.  accumulate_only_touched: for classes
 // with no taps (e.g. 1x1 stride 2) leave din untouched when addend aliases din, else write zeros.
 template <typename T>
 int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* din, const T* addend,
-                      hipStream_t st);
+                      hipStream_t st, DgradFuse* fuse = nullptr);
 
 // The stem conv (7x7 s2 p3, Cin=3) runs as a "virtual" 8x1-tap conv with 32 channels over the padded
 // NHWC4 image produced by stem_pack (see stem.hip).  out = [N][OH][OW][64].

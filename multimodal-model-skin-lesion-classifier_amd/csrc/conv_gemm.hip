@@ -45,11 +45,13 @@ template <int BM, int BN, typename T> constexpr int conv_gemm_lds_bytes() {
   constexpr int ab = 2 * (BM + BN) * 128;
   constexpr int cpitch = BN * (int)sizeof(T) + 16;
   constexpr int rows_per_pass = 256 / (BN / DT<T>::EPC);
-  constexpr int cs = BM * cpitch + 2 * rows_per_pass * BN * 4;
+  constexpr int cs = BM * cpitch + 3 * rows_per_pass * BN * 4;
   return TAP_LDS_BYTES + (ab > cs ? ab : cs);
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+// EPI = 0: plain epilogue (forward conv: store + BN partial sums); EPI = 1: addend and/or the fused
+// BatchNorm-backward mask + sums (dgrad launches).  Separate instantiations keep the forward lean.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p) {
   constexpr int EPC = DT<T>::EPC, BK = DT<T>::BK;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
@@ -206,59 +208,129 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   constexpr int CH_PER_ROW = BN / EPC;
   constexpr int ROWS_PER_PASS = 256 / CH_PER_ROW;
   const int cj = tid % CH_PER_ROW, r0 = tid / CH_PER_ROW;
-  float ssum[EPC], ssq[EPC];
+  float ssum[EPC], ssq[EPC], ssb[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; }
+  for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; ssb[e] = 0.f; }
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
-  const unsigned char* add_b = reinterpret_cast<const unsigned char*>(p.addend);
+  const unsigned char* add_b = EPI ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
+  const unsigned char* my_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
+  const unsigned char* ex_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
+  const unsigned char* ex2_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
+  const bool mask_from_x = EPI && p.ep_scale != nullptr;
+  float esc[EPC], esh[EPC];
+  if (mask_from_x) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { esc[e] = p.ep_scale[n0 + cj * EPC + e]; esh[e] = p.ep_shift[n0 + cj * EPC + e]; }
+  }
   const bool simple_rows = (p.OS == 1 && p.ncls == 1);
   const int ph = p.cls[ci].ph, pw = p.cls[ci].pw;
-  for (int row = r0; row < BM; row += ROWS_PER_PASS) {
-    int m = m0 + row;
-    if (m >= rows) break;
-    int orow = m;
-    if (!simple_rows) {
-      int img = m / ab, rem = m - img * ab;
-      int a = rem / b_dim, b = rem - a * b_dim;
-      orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
-    }
-    Chunk<T> v;
-    v.load(Cs + row * CPITCH + cj * 16);
-    size_t goff = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
-    if (add_b) {
-      Chunk<T> ad;
-      ad.load(add_b + goff);
+  // Rows are handled in groups of EG: all global reads of a group (addend, mask source, BN inputs) are
+  // issued before any of them is consumed, so EG*3 16-byte loads are in flight per lane instead of one
+  // dependent load->store chain per row (the fused epilogue was running at ~3 TB/s that way).
+  constexpr int NR = BM / ROWS_PER_PASS;
+  constexpr int EG = NR < 4 ? NR : 4;
+  static_assert(NR % EG == 0, "row groups");
+  const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
+  for (int grp = 0; grp < NR; grp += EG) {
+    u32x4_t q_ad[EG], q_my[EG], q_x[EG], q_x2[EG];
+    size_t goffs[EG];
+    bool valid[EG];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v.v[e] += ad.v[e];
+    for (int k = 0; k < EG; ++k) {
+      const int row = r0 + (grp + k) * ROWS_PER_PASS;
+      const int m = m0 + row;
+      valid[k] = m < rows;
+      int orow = valid[k] ? m : m0;
+      if (!simple_rows) {
+        int img = orow / ab, rem = orow - img * ab;
+        int a = rem / b_dim, b = rem - a * b_dim;
+        orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
+      }
+      goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
+      if constexpr (EPI) {
+        q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+        q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
+        q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + goffs[k] : zp);
+        q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
+      }
     }
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
-    if (!(abl & 8)) v.store(out_b + goff);
+    for (int k = 0; k < EG; ++k) {
+      if (!valid[k]) continue;
+      const int row = r0 + (grp + k) * ROWS_PER_PASS;
+      Chunk<T> v;
+      v.load(Cs + row * CPITCH + cj * 16);
+      if (add_b) {
+        Chunk<T> ad;
+        ad.from_raw(q_ad[k]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] += ad.v[e];
+      }
+      if (my_b) {
+        Chunk<T> my;
+        my.from_raw(q_my[k]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = my.v[e] > 0.f ? v.v[e] : 0.f;
+      }
+      if (ex_b) {
+        Chunk<T> xv;
+        xv.from_raw(q_x[k]);
+        if (mask_from_x) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v.v[e] = (xv.v[e] * esc[e] + esh[e] > 0.f) ? v.v[e] : 0.f;
+        }
+        // statistics are taken on the value as stored (rounded to T), like the stand-alone reduce kernel
+        Chunk<T> vr = v;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) vr.v[e] = bf16_bits_to_f32(f32_to_bf16_bits(v.v[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { ssum[e] += vr.v[e]; ssq[e] += vr.v[e] * xv.v[e]; }
+        if (ex2_b) {
+          Chunk<T> x2v;
+          x2v.from_raw(q_x2[k]);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) ssb[e] += vr.v[e] * x2v.v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
+      }
+      if (!(abl & 8)) v.store(out_b + goffs[k]);
+    }
   }
   if (p.stat_sum) {
-    float* red = reinterpret_cast<float*>(Cs + BM * CPITCH);  // [2][ROWS_PER_PASS][BN]
+    float* red = reinterpret_cast<float*>(Cs + BM * CPITCH);  // [3][ROWS_PER_PASS][BN]
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       red[r0 * BN + cj * EPC + e] = ssum[e];
       red[(ROWS_PER_PASS + r0) * BN + cj * EPC + e] = ssq[e];
+      if (p.stat_b_sq) red[(2 * ROWS_PER_PASS + r0) * BN + cj * EPC + e] = ssb[e];
     }
     __syncthreads();
     if (tid < BN) {
-      float s = 0.f, q = 0.f;
+      float s = 0.f, q = 0.f, b3 = 0.f;
 #pragma unroll
-      for (int r = 0; r < ROWS_PER_PASS; ++r) { s += red[r * BN + tid]; q += red[(ROWS_PER_PASS + r) * BN + tid]; }
-      p.stat_sum[(size_t)mblk * p.Cout + n0 + tid] = s;
-      p.stat_sq[(size_t)mblk * p.Cout + n0 + tid] = q;
+      for (int r = 0; r < ROWS_PER_PASS; ++r) {
+        s += red[r * BN + tid];
+        q += red[(ROWS_PER_PASS + r) * BN + tid];
+        if (p.stat_b_sq) b3 += red[(2 * ROWS_PER_PASS + r) * BN + tid];
+      }
+      const size_t o = (size_t)mblk * p.stat_stride + n0 + tid;
+      p.stat_sum[o] = s;
+      p.stat_sq[o] = q;
+      if (p.stat_b_sq) { p.stat_b_sum[o] = s; p.stat_b_sq[o] = b3; }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ host
-template <typename T, int BM, int BN, int WMv, int WNv>
+template <typename T, int BM, int BN, int WMv, int WNv, int EPI>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   constexpr int lds = conv_gemm_lds_bytes<BM, BN, T>();
   static bool attr_done = false;
-  auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv>;
+  auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv, EPI>;
   if (!attr_done) {
     HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -287,13 +359,14 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   const bool simple = !(var && !strcmp(var, "pipe"));
   const char* abl = getenv("MMSKIN_CONV_ABLATE");   // timing experiments only
   a.ablate = abl ? atoi(abl) : 0;
-  if (!simple) return launch_conv_pipe<T>(a, st);
+  if (!simple && !a.ep_x) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
+  const bool epi = a.addend || a.ep_mask_y || a.ep_x;
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
-    return launch_cfg<T, CONV_BM, 128, 2, 2>(a, st);
+    return epi ? launch_cfg<T, CONV_BM, 128, 2, 2, 1>(a, st) : launch_cfg<T, CONV_BM, 128, 2, 2, 0>(a, st);
   }
   a.nblk_n = a.Cout / 64;
-  return launch_cfg<T, CONV_BM, 64, 2, 2>(a, st);
+  return epi ? launch_cfg<T, CONV_BM, 64, 2, 2, 1>(a, st) : launch_cfg<T, CONV_BM, 64, 2, 2, 0>(a, st);
 }
 
 static void finish_classes(ConvGemmArgs& a) {
@@ -315,7 +388,7 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
-  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
   a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;
   a.Sy = s.stride; a.Sx = s.stride; a.OS = 1;
@@ -332,13 +405,27 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   return dispatch_conv_gemm<T>(a, st);
 }
 
+int conv_dgrad_partial_rows(const ConvShape& s) {
+  // every parity class rounds its row count up to a whole row block
+  return ceil_div(s.N * s.H * s.W, CONV_BM) + s.stride * s.stride;
+}
+
 template <typename T>
 int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* din, const T* addend,
-                      hipStream_t st) {
+                      hipStream_t st, DgradFuse* fuse) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_dgrad: too many taps");
   ARG_CHECK(s.stride == 1 || s.stride == 2, "conv_dgrad: stride %d unsupported", s.stride);
   ConvGemmArgs a = {};
   a.in = dout; a.w = wt_staged; a.out = din; a.addend = addend;
+  if (fuse) {
+    ARG_CHECK(!(addend == din && addend != nullptr && s.stride != 1 && s.kh == 1),
+              "conv_dgrad: epilogue fusion needs a launch that covers every output pixel");
+    a.ep_mask_y = fuse->mask_y; a.ep_x = fuse->x; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
+    a.ep_x2 = fuse->x2;
+    a.stat_stride = 2 * s.Cin;
+    a.stat_sum = fuse->partial; a.stat_sq = fuse->partial + s.Cin;
+    if (fuse->x2) { a.stat_b_sum = fuse->partial_b; a.stat_b_sq = fuse->partial_b + s.Cin; }
+  }
   a.N = s.N; a.IH = s.OH(); a.IW = s.OW(); a.C = s.Cout; a.Cpitch = s.Cout;
   a.Cout = s.Cin; a.wrow = s.kh * s.kw * s.Cout;
   a.Sy = 1; a.Sx = 1; a.OS = s.stride;
@@ -366,6 +453,7 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
       a.cls[a.ncls++] = c;
     }
   finish_classes(a);
+  if (fuse) fuse->rows_written = a.total_mblk;
   return dispatch_conv_gemm<T>(a, st);
 }
 
@@ -376,7 +464,7 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
   // each reading 32 contiguous elements (8 real pixels x 4 ch) starting at macro pixel wo.
   ConvGemmArgs a = {};
   a.in = img4; a.w = wv; a.out = out; a.addend = nullptr;
-  a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = 64;
   a.N = N; a.IH = Hp; a.IW = Wp / 2; a.C = 32; a.Cpitch = 8;
   a.Cout = 64; a.wrow = 8 * 32;
   a.Sy = 2; a.Sx = 1; a.OS = 1;
@@ -392,7 +480,7 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
 
 #define INST(T)                                                                                      \
   template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t); \
-  template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t);      \
+  template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t, DgradFuse*);      \
   template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);
 INST(float)
 INST(bf16_t)
