@@ -8,6 +8,8 @@
 // lane, which needs no transpose.  The pixel range is split over workgroups; every split writes its
 // own fp32 slab (deterministic, no atomics) and wgrad_reduce sums the slabs straight into the
 // OIHW gradient tensor.
+#include <stdlib.h>
+
 #include "conv.h"
 #include "ops.h"
 
@@ -231,9 +233,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps) {
   BO = (Cout % 128 == 0) ? 128 : 64;
   BKK = (Ktot % 128 == 0) ? 128 : 64;
-  MS *= (BO + BKK == 128) ? 4 : (BO + BKK == 192 ? 2 : 1);   // rows per stage (MSF of the kernel)
+  MS *= (BO + BKK == 128) ? 4 : 2;   // rows per stage (MSF of the kernel)
   int tiles = (Cout / BO) * (Ktot / BKK);
-  int want = ceil_div(1536, tiles);
+  // workgroups to aim for; swept 512..1536 on MI355X (1024 best).  An LDS-DMA staging variant of this
+  // kernel was measured too and was 10 % slower than the register-staged loop kept here.
+  static const int target = [] { const char* v = getenv("MMSKIN_WGRAD_BLOCKS"); return v ? atoi(v) : 1024; }();
+  int want = ceil_div(target, tiles);
   int max_split = M / (MS * 4) > 0 ? M / (MS * 4) : 1;
   nsplit = want < max_split ? want : max_split;
   if (nsplit < 1) nsplit = 1;
@@ -277,7 +282,7 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   int BO, BKK;
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
   int rc;
-  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 1>(a, st);
+  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 2>(a, st);
   else if (BO == 128) rc = launch_wg<T, 128, 64, 2>(a, st);
   else if (BKK == 128) rc = launch_wg<T, 64, 128, 2>(a, st);
   else rc = launch_wg<T, 64, 64, 4>(a, st);
