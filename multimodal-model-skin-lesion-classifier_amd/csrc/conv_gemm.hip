@@ -41,17 +41,22 @@ template <> struct Mma<float> {
 // 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
 __device__ uint4 g_zero_page[16];
 
-template <int BM, int BN, typename T> constexpr int conv_gemm_lds_bytes() {
-  constexpr int ab = 2 * (BM + BN) * 128;
+template <int BM, int BN, typename T, int NST> constexpr int conv_gemm_lds_bytes() {
+  constexpr int ab = NST * (BM + BN) * 128;
   constexpr int cpitch = BN * (int)sizeof(T) + 16;
   constexpr int rows_per_pass = 256 / (BN / DT<T>::EPC);
-  constexpr int cs = BM * cpitch + 3 * rows_per_pass * BN * 4;
-  return TAP_LDS_BYTES + (ab > cs ? ab : cs);
+  constexpr int cs = BM * cpitch;                       // C staging; the stat reduction buffer overlays it
+  constexpr int red = 3 * rows_per_pass * BN * 4;
+  constexpr int m1 = ab > cs ? ab : cs;
+  return TAP_LDS_BYTES + (m1 > red ? m1 : red);
 }
 
 // EPI = 0: plain epilogue (forward conv: store + BN partial sums); EPI = 1: addend and/or the fused
 // BatchNorm-backward mask + sums (dgrad launches).  Separate instantiations keep the forward lean.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+// NST = LDS stages: 2 = double-buffered K loop (2 workgroups per CU); 1 = single buffer, ~35 KB of LDS so
+// 3-4 workgroups share a CU -- for short-K, output-heavy layers where the epilogue dominates and only
+// inter-workgroup overlap can hide it.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NST>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p) {
   constexpr int EPC = DT<T>::EPC, BK = DT<T>::BK;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* s_tap = reinterpret_cast<int*>(smem);
   unsigned char* As = smem + TAP_LDS_BYTES;
-  unsigned char* Bs = As + 2 * A_BYTES;
+  unsigned char* Bs = As + NST * A_BYTES;
 
   const int tid = threadIdx.x;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -154,34 +159,45 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
     for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) LOAD_TILE(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of tile 0 has landed ...
-  __syncthreads();                                   // ... and so has everybody else's
   const unsigned char* Ab0 = As + (wm * WM + l15) * 128;
   const unsigned char* Bb0 = Bs + (wn * WN + l15) * 128;
   const int sw = l15 >> 1;  // (row>>1)&7 for row = 16*f + l15
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) LOAD_TILE(cur ^ 1);   // DMA of the next tile runs under this tile's MFMAs
-    const unsigned char* Ab = Ab0 + cur * A_BYTES;
-    const unsigned char* Bb = Bb0 + cur * B_BYTES;
-    if (!(abl & 4))
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int off = ((4 * s + g) ^ sw) << 4;
-      uint4 fa[FM], fb[FN];
-#pragma unroll
-      for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(Ab + j * 16 * 128 + off);
-#pragma unroll
-      for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(Bb + i * 16 * 128 + off);
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]);
+#define COMPUTE_TILE(cur)                                                                      \
+  do {                                                                                         \
+    const unsigned char* Ab = Ab0 + (cur) * A_BYTES;                                           \
+    const unsigned char* Bb = Bb0 + (cur) * B_BYTES;                                           \
+    if (!(abl & 4))                                                                            \
+      _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                          \
+        const int off = ((4 * s + g) ^ sw) << 4;                                               \
+        uint4 fa[FM], fb[FN];                                                                  \
+        _Pragma("unroll") for (int j = 0; j < FM; ++j) fa[j] = *reinterpret_cast<const uint4*>(Ab + j * 16 * 128 + off); \
+        _Pragma("unroll") for (int i = 0; i < FN; ++i) fb[i] = *reinterpret_cast<const uint4*>(Bb + i * 16 * 128 + off); \
+        _Pragma("unroll") for (int i = 0; i < FN; ++i)                                         \
+          _Pragma("unroll") for (int j = 0; j < FM; ++j) Mma<T>::run(fb[i], fa[j], acc[i][j]); \
+      }                                                                                        \
+  } while (0)
+
+  if constexpr (NST == 2) {
+    if (nk > 0) LOAD_TILE(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of tile 0 has landed ...
+    __syncthreads();                                   // ... and so has everybody else's
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) LOAD_TILE(cur ^ 1);   // DMA of the next tile runs under this tile's MFMAs
+      COMPUTE_TILE(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (it flew under the MFMAs above)
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile landed (it flew under the MFMAs above)
-    __syncthreads();
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      LOAD_TILE(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      COMPUTE_TILE(0);
+      __syncthreads();   // every wave is done with the buffer before it is refilled / reused as C staging
+    }
   }
+#undef COMPUTE_TILE
 #undef LOAD_TILE
 #undef GLDS16
 
@@ -301,7 +317,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     }
   }
   if (p.stat_sum) {
-    float* red = reinterpret_cast<float*>(Cs + BM * CPITCH);  // [3][ROWS_PER_PASS][BN]
+    __syncthreads();                               // all rows of Cs consumed: the reduction buffer overlays it
+    float* red = reinterpret_cast<float*>(Cs);     // [3][ROWS_PER_PASS][BN]
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       red[r0 * BN + cj * EPC + e] = ssum[e];
@@ -326,11 +343,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 }
 
 // ------------------------------------------------------------------------------------------ host
-template <typename T, int BM, int BN, int WMv, int WNv, int EPI>
+template <typename T, int BM, int BN, int WMv, int WNv, int EPI, int NST>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
-  constexpr int lds = conv_gemm_lds_bytes<BM, BN, T>();
+  constexpr int lds = conv_gemm_lds_bytes<BM, BN, T, NST>();
   static bool attr_done = false;
-  auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv, EPI>;
+  auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv, EPI, NST>;
   if (!attr_done) {
     HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -361,12 +378,20 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   a.ablate = abl ? atoi(abl) : 0;
   if (!simple && !a.ep_x) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
   const bool epi = a.addend || a.ep_mask_y || a.ep_x;
+  // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
+  // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
+  // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
+  static const int nst1_min_blocks = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS"); return v ? atoi(v) : 640; }();
+  const int bn_sel = (a.Cout % 128 == 0) ? 128 : 64;
+  const bool one = a.total_mblk * (a.Cout / bn_sel) > nst1_min_blocks;
+#define GO(BNv, E) (one ? launch_cfg<T, CONV_BM, BNv, 2, 2, E, 1>(a, st) : launch_cfg<T, CONV_BM, BNv, 2, 2, E, 2>(a, st))
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
-    return epi ? launch_cfg<T, CONV_BM, 128, 2, 2, 1>(a, st) : launch_cfg<T, CONV_BM, 128, 2, 2, 0>(a, st);
+    return epi ? GO(128, 1) : GO(128, 0);
   }
   a.nblk_n = a.Cout / 64;
-  return epi ? launch_cfg<T, CONV_BM, 64, 2, 2, 1>(a, st) : launch_cfg<T, CONV_BM, 64, 2, 2, 0>(a, st);
+  return epi ? GO(64, 1) : GO(64, 0);
+#undef GO
 }
 
 static void finish_classes(ConvGemmArgs& a) {

@@ -1,0 +1,39 @@
+"""GPU box: time every distinct ResNet-50 forward conv shape (batch 256) and print the count-weighted total.
+Usage: python scripts/conv_mix.py [label]   (kernel variants are selected through MMSKIN_* env vars)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "multimodal-model-skin-lesion-classifier_amd")]
+import torch
+from mmskin import _lib
+from mmskin._lib import ptr, stream
+lib = _lib.load()
+N = 256
+SHAPES = [  # name, count, Cin, H, Cout, k, stride
+    ("l1.c1a 64->64", 1, 64, 56, 64, 1, 1), ("l1.c1b 256->64", 2, 256, 56, 64, 1, 1), ("l1.c2 3x3 64", 3, 64, 56, 64, 3, 1),
+    ("l1.c3 64->256", 4, 64, 56, 256, 1, 1),
+    ("l2.c1a 256->128@56", 1, 256, 56, 128, 1, 1), ("l2.c1b 512->128", 3, 512, 28, 128, 1, 1), ("l2.c2a 3x3s2 128", 1, 128, 56, 128, 3, 2),
+    ("l2.c2 3x3 128", 3, 128, 28, 128, 3, 1), ("l2.c3 128->512", 4, 128, 28, 512, 1, 1), ("l2.ds 256->512s2", 1, 256, 56, 512, 1, 2),
+    ("l3.c1a 512->256@28", 1, 512, 28, 256, 1, 1), ("l3.c1b 1024->256", 5, 1024, 14, 256, 1, 1), ("l3.c2a 3x3s2 256", 1, 256, 28, 256, 3, 2),
+    ("l3.c2 3x3 256", 5, 256, 14, 256, 3, 1), ("l3.c3 256->1024", 6, 256, 14, 1024, 1, 1), ("l3.ds 512->1024s2", 1, 512, 28, 1024, 1, 2),
+    ("l4.c1a 1024->512@14", 1, 1024, 14, 512, 1, 1), ("l4.c1b 2048->512", 2, 2048, 7, 512, 1, 1), ("l4.c2a 3x3s2 512", 1, 512, 14, 512, 3, 2),
+    ("l4.c2 3x3 512", 2, 512, 7, 512, 3, 1), ("l4.c3 512->2048", 3, 512, 7, 2048, 1, 1), ("l4.ds 1024->2048s2", 1, 1024, 14, 2048, 1, 2),
+]
+ws = torch.zeros(2 << 30, dtype=torch.uint8, device="cuda")
+torch.manual_seed(0)
+# random bf16 bit patterns of moderate magnitude (exponent 0x3c..0x3f): realistic MFMA power draw
+hi = torch.randint(0x3c, 0x40, (1 << 29,), dtype=torch.int16, device="cuda") << 8
+lo = torch.randint(0, 256, (1 << 29,), dtype=torch.int16, device="cuda")
+sign = torch.randint(0, 2, (1 << 29,), dtype=torch.int16, device="cuda") << 15
+ws[: 1 << 30].view(torch.int16).copy_(hi | lo | sign)
+del hi, lo, sign
+tot = totf = 0.0
+rows = []
+for name, cnt, Cin, H, Cout, k, s in SHAPES:
+    p = k // 2
+    OH = (H + 2 * p - k) // s + 1
+    fl = 2.0 * N * OH * OH * Cout * Cin * k * k
+    us = lib.mmskin_conv2d_time(N, Cin, H, H, Cout, k, k, s, p, _lib.BF16, 20, ptr(ws), stream())
+    rows.append(f"{name:22s} x{cnt}  {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s")
+    tot += cnt * us; totf += cnt * fl
+print("\n".join(rows))
+print(f"TOTAL[{sys.argv[1] if len(sys.argv) > 1 else ''}] {tot / 1e3:.3f} ms  ({totf / tot / 1e6:.0f} TF/s average)")
