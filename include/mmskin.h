@@ -78,6 +78,8 @@ int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, floa
  * on NHWC buffers carved from `workspace` (>= conv2d_workspace_bytes; contents irrelevant) */
 double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
                           int iters, void* workspace, void* stream);
+double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
+                                int iters, void* workspace, void* stream);
 /* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */
 int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W);
 int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,

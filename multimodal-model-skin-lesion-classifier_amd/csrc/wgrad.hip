@@ -36,118 +36,13 @@ __device__ __forceinline__ uint2 lds_read_tr16_b64(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-// MSF scales the rows staged per barrier: small output tiles stage more pixel rows per step so every
-// barrier-to-barrier interval carries >= 16 MFMAs per wave and 16-32 KB of loads (a 64x64 tile with 32
-// rows per step was latency-bound at 48 TF/s).
-template <typename T, int BO, int BKK, int MSF>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
-  constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS * MSF;
+// One staged block of MS pixel rows: acc[kidx frag][cout frag] += Y^T X  (fragments via transposing LDS reads)
+template <typename T, int BO, int BKK, int MS>
+__device__ __forceinline__ void wg_compute(const unsigned char* Xb, const unsigned char* Yb,
+                                           f32x4_t (&acc)[BKK / 32][BO / 32], int wo, int wk, int l15, int g) {
   constexpr int PX = BO * (int)sizeof(T), PY = BKK * (int)sizeof(T);
-  constexpr int X_BYTES = MS * PX, Y_BYTES = MS * PY;
-  constexpr int CPR_X = BO / EPC, CPR_Y = BKK / EPC;  // chunks per row
-  constexpr int NX = MS * CPR_X / 256 > 0 ? MS * CPR_X / 256 : 1;
-  constexpr int NY = MS * CPR_Y / 256 > 0 ? MS * CPR_Y / 256 : 1;
-  static_assert(MS * CPR_X % 256 == 0 && MS * CPR_Y % 256 == 0, "tile/thread mismatch");
-  constexpr int FO = BO / 32, FK = BKK / 32;  // 16-wide fragments per wave (2x2 waves)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + Y_BYTES)];
-  unsigned char* Xs = smem;
-  unsigned char* Ys = smem + 2 * X_BYTES;
-
-  const int tid = threadIdx.x;
-  int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int kb = tile % p.nblk_k; tile /= p.nblk_k;
-  const int ob = tile % p.nblk_o;
-  const int split = tile / p.nblk_o;
-  const int o0 = ob * BO, k0 = kb * BKK;
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
-
-  // ---- X loader (dY rows): chunk idx = tid + 256*i
-  int x_row[NX], x_ch[NX];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) { int idx = tid + 256 * i; x_row[i] = idx / CPR_X; x_ch[i] = idx - x_row[i] * CPR_X; }
-  // ---- Y loader (gathered input rows)
-  int y_row[NY], y_ch[NY], y_c[NY], y_oy[NY], y_ox[NY], y_img[NY], y_dy[NY], y_dx[NY];
-  const int ohw = p.OH * p.OW;
-#pragma unroll
-  for (int i = 0; i < NY; ++i) {
-    int idx = tid + 256 * i;
-    y_row[i] = idx / CPR_Y; y_ch[i] = idx - y_row[i] * CPR_Y;
-    int kidx = k0 + y_ch[i] * EPC;
-    int tap = kidx / p.C;
-    y_c[i] = kidx - tap * p.C;
-    y_dy[i] = p.offy[tap]; y_dx[i] = p.offx[tap];
-    int m = m_begin + y_row[i];
-    int img = m / ohw, rem = m - img * ohw;
-    y_img[i] = img; y_oy[i] = rem / p.OW; y_ox[i] = rem - y_oy[i] * p.OW;
-  }
-  const unsigned char* dy_b = reinterpret_cast<const unsigned char*>(p.dy);
-  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-
-  // named staging registers (arrays of uint4 ended up in scratch memory)
-  static_assert(NX <= 4 && NY <= 4 && NX != 3 && NY != 3, "staging registers are written out for 1, 2 or 4 chunks per thread");
-  u32x4_t rx0, rx1, rx2, rx3, ry0, ry1, ry2, ry3;
-  int m_stage = m_begin;  // first row of the stage the next LOAD_STAGE() fetches
-  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_wzero_page);
-  const int OWr = p.OW, OHr = p.OH;
-
-#define LOAD_X(i, R)                                                                                   \
-  {                                                                                                    \
-    const int m = m_stage + x_row[i];                                                                  \
-    const unsigned char* src = dy_b + ((size_t)m * p.Cout + o0 + x_ch[i] * EPC) * sizeof(T);           \
-    R = *reinterpret_cast<const u32x4_t*>(m < m_end ? src : zero_page);                                \
-  }
-#define LOAD_Y(i, R)                                                                                   \
-  {                                                                                                    \
-    const int m = m_stage + y_row[i];                                                                  \
-    const int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];                            \
-    const bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;       \
-    const unsigned char* src =                                                                         \
-        in_b + ((int64_t)((y_img[i] * p.IH + iy) * p.IW + ix) * p.Cpitch + y_c[i]) * (int)sizeof(T);   \
-    R = *reinterpret_cast<const u32x4_t*>(ok ? src : zero_page);                                       \
-    /* advance this row's pixel by MS for the next stage */                                            \
-    int nx = y_ox[i] + MS;                                                                             \
-    const int qy = nx / OWr;                                                                           \
-    nx -= qy * OWr;                                                                                    \
-    const int ny = y_oy[i] + qy;                                                                       \
-    const int qi = ny / OHr;                                                                           \
-    y_ox[i] = nx; y_oy[i] = ny - qi * OHr; y_img[i] += qi;                                             \
-  }
-#define LOAD_STAGE()                                                                                   \
-  do {                                                                                                 \
-    LOAD_X(0, rx0) if constexpr (NX > 1) LOAD_X(1 % NX, rx1)                                           \
-    if constexpr (NX > 2) { LOAD_X(2 % NX, rx2) LOAD_X(3 % NX, rx3) }                                  \
-    LOAD_Y(0, ry0) if constexpr (NY > 1) LOAD_Y(1 % NY, ry1)                                           \
-    if constexpr (NY > 2) { LOAD_Y(2 % NY, ry2) LOAD_Y(3 % NY, ry3) }                                  \
-    m_stage += MS;                                                                                     \
-  } while (0)
-#define ST_X(buf, i, R) *reinterpret_cast<u32x4_t*>(Xs + (buf) * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = R;
-#define ST_Y(buf, i, R) *reinterpret_cast<u32x4_t*>(Ys + (buf) * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = R;
-#define STORE_STAGE(buf)                                                                               \
-  do {                                                                                                 \
-    ST_X(buf, 0, rx0) if constexpr (NX > 1) ST_X(buf, 1 % NX, rx1)                                     \
-    if constexpr (NX > 2) { ST_X(buf, 2 % NX, rx2) ST_X(buf, 3 % NX, rx3) }                            \
-    ST_Y(buf, 0, ry0) if constexpr (NY > 1) ST_Y(buf, 1 % NY, ry1)                                     \
-    if constexpr (NY > 2) { ST_Y(buf, 2 % NY, ry2) ST_Y(buf, 3 % NY, ry3) }                            \
-  } while (0)
-
-  const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  const int wo = wid >> 1, wk = wid & 1;  // wave position: cout half, k half
-  f32x4_t acc[FK][FO];
-#pragma unroll
-  for (int i = 0; i < FK; ++i)
-#pragma unroll
-    for (int j = 0; j < FO; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nstage = (m_end - m_begin + MS - 1) / MS;
-  if (nstage > 0) { LOAD_STAGE(); STORE_STAGE(0); }
-  __syncthreads();
-  for (int s = 0; s < nstage; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nstage) LOAD_STAGE();
-    const unsigned char* Xb = Xs + cur * X_BYTES;
-    const unsigned char* Yb = Ys + cur * Y_BYTES;
-    if constexpr (sizeof(T) == 2) {
+  constexpr int FO = BO / 32, FK = BKK / 32;
+  if constexpr (sizeof(T) == 2) {
       // transposing reads: lane (q,pp) of a 16-lane group addresses row q, columns 4pp..4pp+3 of a
       // 4x16 block; lane i receives column i of the 4 rows.  Two reads give k = 8g .. 8g+7.
       const int q = l15 >> 2, pp = l15 & 3;
@@ -198,12 +93,156 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fy[i], fx[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (s + 1 < nstage) STORE_STAGE(cur ^ 1);
+}
+
+// MSF scales the rows staged per barrier: small output tiles stage more pixel rows per step so every
+// barrier-to-barrier interval carries >= 16 MFMAs per wave and 16-32 KB of loads (a 64x64 tile with 32
+// rows per step was latency-bound at 48 TF/s).
+// PF = stages kept in flight in registers (1 or 2).
+template <typename T, int BO, int BKK, int MSF, int PF>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+  constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS * MSF;
+  constexpr int PX = BO * (int)sizeof(T), PY = BKK * (int)sizeof(T);
+  constexpr int X_BYTES = MS * PX, Y_BYTES = MS * PY;
+  constexpr int CPR_X = BO / EPC, CPR_Y = BKK / EPC;  // chunks per row
+  constexpr int NX = MS * CPR_X / 256 > 0 ? MS * CPR_X / 256 : 1;
+  constexpr int NY = MS * CPR_Y / 256 > 0 ? MS * CPR_Y / 256 : 1;
+  static_assert(MS * CPR_X % 256 == 0 && MS * CPR_Y % 256 == 0, "tile/thread mismatch");
+  constexpr int FO = BO / 32, FK = BKK / 32;  // 16-wide fragments per wave (2x2 waves)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (X_BYTES + Y_BYTES)];
+  unsigned char* Xs = smem;
+  unsigned char* Ys = smem + 2 * X_BYTES;
+
+  const int tid = threadIdx.x;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = tile % p.nblk_k; tile /= p.nblk_k;
+  const int ob = tile % p.nblk_o;
+  const int split = tile / p.nblk_o;
+  const int o0 = ob * BO, k0 = kb * BKK;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  // ---- X loader (dY rows): chunk idx = tid + 256*i
+  int x_row[NX], x_ch[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) { int idx = tid + 256 * i; x_row[i] = idx / CPR_X; x_ch[i] = idx - x_row[i] * CPR_X; }
+  // ---- Y loader (gathered input rows)
+  int y_row[NY], y_ch[NY], y_c[NY], y_oy[NY], y_ox[NY], y_img[NY], y_dy[NY], y_dx[NY];
+  const int ohw = p.OH * p.OW;
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    int idx = tid + 256 * i;
+    y_row[i] = idx / CPR_Y; y_ch[i] = idx - y_row[i] * CPR_Y;
+    int kidx = k0 + y_ch[i] * EPC;
+    int tap = kidx / p.C;
+    y_c[i] = kidx - tap * p.C;
+    y_dy[i] = p.offy[tap]; y_dx[i] = p.offx[tap];
+    int m = m_begin + y_row[i];
+    int img = m / ohw, rem = m - img * ohw;
+    y_img[i] = img; y_oy[i] = rem / p.OW; y_ox[i] = rem - y_oy[i] * p.OW;
+  }
+  const unsigned char* dy_b = reinterpret_cast<const unsigned char*>(p.dy);
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+
+  // Named staging registers (arrays of uint4 ended up in scratch memory), TWO sets: the kernel was
+  // load-latency bound (ablation: removing the global loads saved 38 %, removing every MFMA 9 % -- the Y
+  // operand is forward activations coming cold from HBM), so stages s+1 AND s+2 are kept in flight while
+  // stage s is multiplied; the loop is unrolled by two so each set has a fixed name.
+  static_assert(NX <= 4 && NY <= 4 && NX != 3 && NY != 3, "staging registers are written out for 1, 2 or 4 chunks per thread");
+  const u32x4_t z4 = {0, 0, 0, 0};
+  u32x4_t rxA0 = z4, rxA1 = z4, rxA2 = z4, rxA3 = z4, ryA0 = z4, ryA1 = z4, ryA2 = z4, ryA3 = z4;
+  u32x4_t rxB0 = z4, rxB1 = z4, rxB2 = z4, rxB3 = z4, ryB0 = z4, ryB1 = z4, ryB2 = z4, ryB3 = z4;
+  const int abl = p.ablate;
+  int m_stage = m_begin;  // first row of the stage the next LOAD_STAGE() fetches
+  const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_wzero_page);
+  const int OWr = p.OW, OHr = p.OH;
+  const int inv_ow = (65536 + OWr - 1) / OWr, inv_oh = (65536 + OHr - 1) / OHr;
+
+#define LOAD_X(i, R)                                                                                   \
+  {                                                                                                    \
+    const int m = m_stage + x_row[i];                                                                  \
+    const unsigned char* src = dy_b + ((size_t)m * p.Cout + o0 + x_ch[i] * EPC) * sizeof(T);           \
+    R = *reinterpret_cast<const u32x4_t*>(m < m_end ? src : zero_page);                                \
+  }
+#define LOAD_Y(i, R)                                                                                   \
+  {                                                                                                    \
+    const int m = m_stage + y_row[i];                                                                  \
+    const int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];                            \
+    const bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;       \
+    const unsigned char* src =                                                                         \
+        in_b + ((int64_t)((y_img[i] * p.IH + iy) * p.IW + ix) * p.Cpitch + y_c[i]) * (int)sizeof(T);   \
+    R = *reinterpret_cast<const u32x4_t*>(ok ? src : zero_page);                                       \
+    /* advance this row's pixel by MS for the next stage; the quotients come from 16-bit reciprocal     \
+       multiplies (exact for these ranges): two hardware-less integer divisions per chunk per stage     \
+       cost more VALU time than the stage's 32 MFMAs */                                                \
+    int nx = y_ox[i] + MS;                                                                             \
+    const int qy = (nx * inv_ow) >> 16;                                                                \
+    nx -= qy * OWr;                                                                                    \
+    const int ny = y_oy[i] + qy;                                                                       \
+    const int qi = (ny * inv_oh) >> 16;                                                                \
+    y_ox[i] = nx; y_oy[i] = ny - qi * OHr; y_img[i] += qi;                                             \
+  }
+#define LOAD_STAGE(S)                                                                                  \
+  do {                                                                                                 \
+    if (!(abl & 1)) { LOAD_X(0, rx##S##0) if constexpr (NX > 1) LOAD_X(1 % NX, rx##S##1)               \
+    if constexpr (NX > 2) { LOAD_X(2 % NX, rx##S##2) LOAD_X(3 % NX, rx##S##3) } }                      \
+    if (!(abl & 2)) { LOAD_Y(0, ry##S##0) if constexpr (NY > 1) LOAD_Y(1 % NY, ry##S##1)               \
+    if constexpr (NY > 2) { LOAD_Y(2 % NY, ry##S##2) LOAD_Y(3 % NY, ry##S##3) } }                      \
+    m_stage += MS;                                                                                     \
+  } while (0)
+#define ST_X(buf, i, R) *reinterpret_cast<u32x4_t*>(Xs + (buf) * X_BYTES + x_row[i] * PX + ((x_ch[i] ^ wg_swz<T, PX>(x_row[i])) << 4)) = R;
+#define ST_Y(buf, i, R) *reinterpret_cast<u32x4_t*>(Ys + (buf) * Y_BYTES + y_row[i] * PY + ((y_ch[i] ^ wg_swz<T, PY>(y_row[i])) << 4)) = R;
+#define STORE_STAGE(buf, S)                                                                            \
+  if (!(abl & 16)) do {                                                                                \
+    ST_X(buf, 0, rx##S##0) if constexpr (NX > 1) ST_X(buf, 1 % NX, rx##S##1)                           \
+    if constexpr (NX > 2) { ST_X(buf, 2 % NX, rx##S##2) ST_X(buf, 3 % NX, rx##S##3) }                  \
+    ST_Y(buf, 0, ry##S##0) if constexpr (NY > 1) ST_Y(buf, 1 % NY, ry##S##1)                           \
+    if constexpr (NY > 2) { ST_Y(buf, 2 % NY, ry##S##2) ST_Y(buf, 3 % NY, ry##S##3) }                  \
+  } while (0)
+
+  const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int wo = wid >> 1, wk = wid & 1;  // wave position: cout half, k half
+  f32x4_t acc[FK][FO];
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FO; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nstage = (m_end - m_begin + MS - 1) / MS;
+  static_assert(PF == 1 || PF == 2, "prefetch depth");
+  if constexpr (PF == 2) {
+    if (nstage > 0) { LOAD_STAGE(A); STORE_STAGE(0, A); }
+    if (nstage > 1) LOAD_STAGE(A);          // stage 1 -> set A
+    if (nstage > 2) LOAD_STAGE(B);          // stage 2 -> set B
     __syncthreads();
+    for (int s = 0; s < nstage; s += 2) {
+      // LDS[0] holds stage s, set A holds stage s+1, set B holds stage s+2 (in flight)
+      if (!(abl & 4)) wg_compute<T, BO, BKK, MS>(Xs, Ys, acc, wo, wk, l15, g);
+      if (s + 1 < nstage) STORE_STAGE(1, A);
+      __syncthreads();
+      if (s + 3 < nstage) LOAD_STAGE(A);    // stage s+3
+      if (s + 1 >= nstage) break;
+      // LDS[1] holds stage s+1, set B holds stage s+2, set A holds stage s+3 (in flight)
+      if (!(abl & 4)) wg_compute<T, BO, BKK, MS>(Xs + X_BYTES, Ys + Y_BYTES, acc, wo, wk, l15, g);
+      if (s + 2 < nstage) STORE_STAGE(0, B);
+      __syncthreads();
+      if (s + 4 < nstage) LOAD_STAGE(B);    // stage s+4
+    }
+  } else {
+    if (nstage > 0) { LOAD_STAGE(A); STORE_STAGE(0, A); }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < nstage) LOAD_STAGE(A);    // in flight while this stage is multiplied
+      if (!(abl & 4)) wg_compute<T, BO, BKK, MS>(Xs + cur * X_BYTES, Ys + cur * Y_BYTES, acc, wo, wk, l15, g);
+      if (s + 1 < nstage) STORE_STAGE(cur ^ 1, A);
+      __syncthreads();
+    }
   }
 
   // D[i = k index][j = cout]: lane holds cout = l15, k = g*4 + reg  -> float4 along k in the slab
   float* slab = p.slab + (size_t)split * p.Cout * p.Ktot;
+  if (abl & 8) return;
 #pragma unroll
   for (int i = 0; i < FK; ++i)
 #pragma unroll
@@ -270,17 +309,23 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
   a.nblk_o = a.Cout / BO;
   a.nblk_k = a.Ktot / BKK;
   int grid = a.nblk_o * a.nblk_k * a.nsplit;
-  hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF>), dim3(grid), dim3(256), 0, st, a);
+  // two-deep prefetch measured no faster in isolation and slower inside the training step (224 VGPRs)
+  static const int pf = [] { const char* v = getenv("MMSKIN_WGRAD_PF"); return v ? atoi(v) : 1; }();
+  if (pf == 2) hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF, 2>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF, 1>), dim3(grid), dim3(256), 0, st, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
+
 
 template <typename T>
 static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_layout, hipStream_t st) {
   ARG_CHECK(a.Cout % 64 == 0 && a.Ktot % 64 == 0, "wgrad: Cout=%d Ktot=%d must be multiples of 64", a.Cout, a.Ktot);
   ARG_CHECK(a.C % DT<T>::EPC == 0, "wgrad: C=%d", a.C);
+  ARG_CHECK(a.OW <= 240 && a.OH <= 240, "wgrad: output %dx%d too large for the 16-bit reciprocal pixel stepping", a.OH, a.OW);
   int BO, BKK;
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
+  { const char* v = getenv("MMSKIN_WGRAD_ABLATE"); a.ablate = v ? atoi(v) : 0; }
   int rc;
   if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 2>(a, st);
   else if (BO == 128) rc = launch_wg<T, 128, 64, 2>(a, st);

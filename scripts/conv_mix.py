@@ -1,4 +1,4 @@
-"""GPU box: time every distinct ResNet-50 forward conv shape (batch 256) and print the count-weighted total.
+"""GPU box: time every distinct ResNet-50 conv shape (batch 256) and print the count-weighted total (MMSKIN_MIX_OP=fwd|wgrad).
 Usage: python scripts/conv_mix.py [label]   (kernel variants are selected through MMSKIN_* env vars)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ SHAPES = [  # name, count, Cin, H, Cout, k, stride
     ("l4.c1a 1024->512@14", 1, 1024, 14, 512, 1, 1), ("l4.c1b 2048->512", 2, 2048, 7, 512, 1, 1), ("l4.c2a 3x3s2 512", 1, 512, 14, 512, 3, 2),
     ("l4.c2 3x3 512", 2, 512, 7, 512, 3, 1), ("l4.c3 512->2048", 3, 512, 7, 2048, 1, 1), ("l4.ds 1024->2048s2", 1, 1024, 14, 2048, 1, 2),
 ]
-ws = torch.zeros(2 << 30, dtype=torch.uint8, device="cuda")
+ws = torch.zeros(3 << 30, dtype=torch.uint8, device="cuda")
 torch.manual_seed(0)
 # random bf16 bit patterns of moderate magnitude (exponent 0x3c..0x3f): realistic MFMA power draw
 hi = torch.randint(0x3c, 0x40, (1 << 29,), dtype=torch.int16, device="cuda") << 8
@@ -32,7 +32,8 @@ for name, cnt, Cin, H, Cout, k, s in SHAPES:
     p = k // 2
     OH = (H + 2 * p - k) // s + 1
     fl = 2.0 * N * OH * OH * Cout * Cin * k * k
-    us = lib.mmskin_conv2d_time(N, Cin, H, H, Cout, k, k, s, p, _lib.BF16, 20, ptr(ws), stream())
+    fn = lib.mmskin_conv2d_wgrad_time if os.environ.get("MMSKIN_MIX_OP") == "wgrad" else lib.mmskin_conv2d_time
+    us = fn(N, Cin, H, H, Cout, k, k, s, p, _lib.BF16, 20, ptr(ws), stream())
     rows.append(f"{name:22s} x{cnt}  {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s")
     tot += cnt * us; totf += cnt * fl
 print("\n".join(rows))
