@@ -63,8 +63,27 @@ struct Profiler {
   void reset() { used = 0; cls.clear(); for (int i = 0; i < K_NCLASS; ++i) { flops[i] = 0; bytes[i] = 0; } }
 };
 
+// Weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream beside the
+// dgrad -> BN-backward chain of the main stream (fills launch tails and latency-bound phases).
+struct SideStream {
+  hipStream_t s = nullptr;
+  hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // main: buffer i holds a fresh dX
+  hipEvent_t done[3] = {nullptr, nullptr, nullptr};    // side: the wgrad reading buffer i has finished
+  bool done_valid[3] = {false, false, false};
+  int init() {
+    if (s) return MMSKIN_OK;
+    HIP_CHECK_RET(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) {
+      HIP_CHECK_RET(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    }
+    return MMSKIN_OK;
+  }
+};
+
 struct Plan {
   Profiler prof;
+  SideStream side;
   int arch, N, H, W, dtype;
   int feat_dim;
   int Hp, Wp, OH0, OW0, PH, PW;
@@ -78,7 +97,7 @@ struct Plan {
   int64_t staged_elems = 0;
   // workspace layout (bytes)
   size_t ws_bytes = 0;
-  size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[6], off_slab, off_partial,
+  size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[7], off_slab, off_partial,
       off_coefbwd, off_dwv, off_red, off_partial_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
   size_t esz() const { return dtype == 1 ? 2 : 4; }
@@ -220,7 +239,7 @@ int build_plan(Plan& p) {
     }
     prev = p.units[b.units.back()].y_off;
   }
-  for (int i = 0; i < 6; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
+  for (int i = 0; i < 7; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
   p.off_slab = carve(cur, slab_max);
   p.off_partial = carve(cur, partial_max);
   p.off_partial_b = carve(cur, partial_max);
@@ -339,8 +358,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   float* slab = reinterpret_cast<float*>(ws + p.off_slab);
   float* partial = reinterpret_cast<float*>(ws + p.off_partial);
   float* cA = reinterpret_cast<float*>(ws + p.off_coefbwd);
-  T* S[6];
-  for (int i = 0; i < 6; ++i) S[i] = reinterpret_cast<T*>(ws + p.off_scratch[i]);
+  T* S[7];
+  for (int i = 0; i < 7; ++i) S[i] = reinterpret_cast<T*>(ws + p.off_scratch[i]);
   int rc;
 
   // BN backward of unit u given dy: fills dx (and optionally dz)
@@ -382,6 +401,37 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   T* gin = S[1];
   if ((rc = avgpool_bwd<T>(dfeat, p.N, last.s.OH() * last.s.OW(), last.s.Cout, g, st))) return rc;
 
+  // ---- side stream for the weight-gradient GEMMs (buffers: 0/1 = alternating dX, 2 = downsample dX)
+  static const bool side_off = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
+  const bool use_side = !side_off && !p.prof.on;
+  if (use_side && (rc = p.side.init())) return rc;
+  for (int i = 0; i < 3; ++i) p.side.done_valid[i] = false;
+  T* DX[3] = {S[2], S[6], S[5]};
+  // main stream may overwrite buffer i only after the wgrad that reads it has finished
+  auto acquire = [&](int i) -> int {
+    if (use_side && p.side.done_valid[i]) HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.done[i], 0));
+    return MMSKIN_OK;
+  };
+  auto wgrad_async = [&](Unit& u, int i, const T* uin) -> int {
+    hipStream_t ws_st = st;
+    if (use_side) {
+      HIP_CHECK_RET(hipEventRecord(p.side.ready[i], st));
+      HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.ready[i], 0));
+      ws_st = p.side.s;
+    }
+    p.prof.begin(K_WGRAD, st);
+    int r = launch_conv_wgrad<T>(u.s, DX[i], uin, slab, grads + u.w_off, ws_st);
+    p.prof.end(st);
+    if (p.prof.on) p.prof.flops[K_WGRAD] += conv_flops(u.s);
+    if (r) return r;
+    if (use_side) {
+      HIP_CHECK_RET(hipEventRecord(p.side.done[i], p.side.s));
+      p.side.done_valid[i] = true;
+    }
+    return MMSKIN_OK;
+  };
+  int dxi = 0;   // index of the buffer holding the current dX
+
   bool fused_ready = false;   // g already holds the masked dz of this block's final unit, partials in the slabs
   int fused_rows = 0;
   for (int bi = (int)p.blocks.size() - 1; bi >= 0; --bi) {
@@ -390,12 +440,15 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     const T* in = reinterpret_cast<const T*>(ws + b.in_off);
     Unit& ul = p.units[b.units[nu - 1]];
     const T* out = reinterpret_cast<const T*>(ws + ul.y_off);
-    T* dX = S[2];
     T* dY = S[3];
     T* dZ = S[4];
-    T* dXd = S[5];
+    T* dXd = DX[2];
     const bool has_ds = b.ds >= 0;
     const T* dz_final;   // masked gradient of the block output (residual branch addend)
+    dxi ^= 1;
+    if ((rc = acquire(dxi))) return rc;
+    if (has_ds && (rc = acquire(2))) return rc;
+    T* dX = DX[dxi];
     if (fused_ready) {
       if ((rc = bn_backward_fused(ul, g, partial, fused_rows, dX))) return rc;
       if (has_ds)
@@ -410,7 +463,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     for (int i = nu - 1; i >= 0; --i) {
       Unit& u = p.units[b.units[i]];
       const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
-      PROF(K_WGRAD, conv_flops(u.s), 0.0, launch_conv_wgrad<T>(u.s, dX, uin, slab, grads + u.w_off, st));
+      if ((rc = wgrad_async(u, dxi, uin))) return rc;
       if (i > 0) {
         // dgrad writes the gradient of unit i-1's ReLU output; its epilogue applies that ReLU's mask and
         // accumulates unit i-1's BN-backward sums, so the stand-alone reduce pass is gone.
@@ -419,12 +472,15 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         DgradFuse f;
         f.x = ws + up.x_off; f.scale = cup; f.shift = cup + up.s.Cout; f.partial = partial;
         PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st, &f));
+        dxi ^= 1;                              // the next dX goes to the other buffer: wgrad(u) may still read this one
+        if ((rc = acquire(dxi))) return rc;
+        dX = DX[dxi];
         if ((rc = bn_backward_fused(up, dY, partial, f.rows_written, dX))) return rc;
       } else {
         const T* addend = dz_final;
         if (has_ds) {
           Unit& d = p.units[b.ds];
-          PROF(K_WGRAD, conv_flops(d.s), 0.0, launch_conv_wgrad<T>(d.s, dXd, in, slab, grads + d.w_off, st));
+          if ((rc = wgrad_async(d, 2, in))) return rc;
           PROF(K_CONV_DGRAD, conv_flops(d.s), 0.0, launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
           addend = gin;   // main-branch dgrad accumulates on top, in place
         }
@@ -444,6 +500,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     }
     T* t = g; g = gin; gin = t;
   }
+
+  // join: the stem reuses the scratch buffers and the slab the side stream has been working on
+  for (int i = 0; i < 3; ++i)
+    if ((rc = acquire(i))) return rc;
 
   // ---- stem: g = grad wrt pooled activation
   Unit& u0 = p.units[0];
@@ -486,6 +546,10 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
 void mmskin_backbone_destroy(mmskin_backbone_t h) {
   if (!h) return;
   if (h->plan.table_dev) (void)hipFree(h->plan.table_dev);
+  if (h->plan.side.s) {
+    for (int i = 0; i < 3; ++i) { (void)hipEventDestroy(h->plan.side.ready[i]); (void)hipEventDestroy(h->plan.side.done[i]); }
+    (void)hipStreamDestroy(h->plan.side.s);
+  }
   delete h;
 }
 
