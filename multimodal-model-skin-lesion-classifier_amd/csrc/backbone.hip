@@ -7,6 +7,7 @@
 // backward.  Parameters stay fp32 masters in one flat buffer laid out in torchvision's
 // named_parameters() order; they are re-staged to the compute dtype (K-contiguous GEMM operands) at
 // the start of every forward.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -72,7 +73,13 @@ struct SideStream {
   bool done_valid[3] = {false, false, false};
   int init() {
     if (s) return MMSKIN_OK;
-    HIP_CHECK_RET(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* v = getenv("MMSKIN_SIDE_PRIORITY");   // "normal" (default) | "high" | "low": no measurable difference
+    int prio = 0;
+    if (v && !strcmp(v, "high")) prio = greatest;
+    if (v && !strcmp(v, "low")) prio = least;
+    HIP_CHECK_RET(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
     for (int i = 0; i < 3; ++i) {
       HIP_CHECK_RET(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming));
       HIP_CHECK_RET(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
