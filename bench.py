@@ -161,9 +161,20 @@ def main():
         n_launch = (ln[0] + ln[1]) // nprof
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        dom_by = (by[0] + by[1]) / nprof
+        traffic = None
+        try:   # per-launch HBM bytes from the committed PMC pass (FETCH_SIZE x2 + WRITE_SIZE, see profiles/)
+            with open(os.path.join(ROOT, "profiles", "conv_gemm_traffic.json")) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": None, "launches_per_step": int(n_launch),
+                    "traffic": traffic, "launches_per_step": int(n_launch),
+                    "algorithmic_gbytes_per_launch": round(dom_by / max(n_launch, 1) / 1e9, 4),
+                    "algorithmic_gbps": round(dom_by / (dom_ms * 1e-3) / 1e9, 1),
+                    "hbm_floor_ms": round(dom_by / 6.3e12 * 1e3, 3), "mfma_floor_ms": round(dom_fl / (peak * 1e12) * 1e3, 3),
+                    "measured_ms": round(dom_ms, 3),
                     "avg_launch_us": round(dom_ms * 1e3 / max(n_launch, 1), 2),
                     "algorithmic_gflop_per_launch": round(dom_fl / max(n_launch, 1) / 1e9, 3),
                     "classes": classes}

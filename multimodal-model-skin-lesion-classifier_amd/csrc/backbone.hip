@@ -269,6 +269,12 @@ int build_plan(Plan& p) {
 static inline double conv_flops(const ConvShape& s) {
   return 2.0 * s.N * s.OH() * s.OW() * (double)s.Cout * s.Cin * s.kh * s.kw;
 }
+// algorithmic HBM bytes of one conv GEMM pass: input once, output once, weights once, plus `extra`
+// input-shaped tensors read by a fused dgrad epilogue (addend, mask source, BN inputs)
+static inline double conv_bytes(const ConvShape& s, size_t es, int extra_in_shaped = 0) {
+  double in = (double)s.N * s.H * s.W * s.Cin, out = (double)s.N * s.OH() * s.OW() * s.Cout;
+  return (in * (1 + extra_in_shaped) + out) * es + (double)s.Cout * s.Cin * s.kh * s.kw * es;
+}
 
 int ensure_table(Plan& p) {
   if (p.table_dev) return MMSKIN_OK;
@@ -310,7 +316,7 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
   PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
-  PROF(K_CONV_FWD, conv_flops(u0.s), 0.0,
+  PROF(K_CONV_FWD, conv_flops(u0.s), conv_bytes(u0.s, sizeof(T)),
        launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
                                training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
   if ((rc = bn_coeffs(u0, stem_conv_stat_rows(p.N, p.OH0, p.OW0)))) return rc;
@@ -325,7 +331,7 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
     const int nu = (int)b.units.size();
     if (b.ds >= 0) {
       Unit& d = p.units[b.ds];
-      PROF(K_CONV_FWD, conv_flops(d.s), 0.0,
+      PROF(K_CONV_FWD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)),
            launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
                               training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
       if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
@@ -334,7 +340,7 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
       Unit& u = p.units[b.units[i]];
       T* x = reinterpret_cast<T*>(ws + u.x_off);
       T* y = reinterpret_cast<T*>(ws + u.y_off);
-      PROF(K_CONV_FWD, conv_flops(u.s), 0.0,
+      PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
            launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
                               training ? stat_sq : nullptr, st));
       if ((rc = bn_coeffs(u, conv_fwd_stat_rows(u.s)))) return rc;
@@ -429,7 +435,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     p.prof.begin(K_WGRAD, st);
     int r = launch_conv_wgrad<T>(u.s, DX[i], uin, slab, grads + u.w_off, ws_st);
     p.prof.end(st);
-    if (p.prof.on) p.prof.flops[K_WGRAD] += conv_flops(u.s);
+    if (p.prof.on) { p.prof.flops[K_WGRAD] += conv_flops(u.s); p.prof.bytes[K_WGRAD] += conv_bytes(u.s, sizeof(T)); }
     if (r) return r;
     if (use_side) {
       HIP_CHECK_RET(hipEventRecord(p.side.done[i], p.side.s));
@@ -478,7 +484,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         float* cup = reinterpret_cast<float*>(ws + up.coef_off);
         DgradFuse f;
         f.x = ws + up.x_off; f.scale = cup; f.shift = cup + up.s.Cout; f.partial = partial;
-        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st, &f));
+        PROF(K_CONV_DGRAD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 1), launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st, &f));
         dxi ^= 1;                              // the next dX goes to the other buffer: wgrad(u) may still read this one
         if ((rc = acquire(dxi))) return rc;
         dX = DX[dxi];
@@ -488,7 +494,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if (has_ds) {
           Unit& d = p.units[b.ds];
           if ((rc = wgrad_async(d, 2, in))) return rc;
-          PROF(K_CONV_DGRAD, conv_flops(d.s), 0.0, launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
+          PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
           addend = gin;   // main-branch dgrad accumulates on top, in place
         }
         DgradFuse f;
@@ -500,7 +506,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
           if (pb.ds >= 0) { f.x2 = ws + p.units[pb.ds].x_off; f.partial_b = partial_b; }
           fp = &f;
         }
-        PROF(K_CONV_DGRAD, conv_flops(u.s), 0.0, launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, addend, st, fp));
+        PROF(K_CONV_DGRAD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 1 + (fp ? (f.x2 ? 3 : 2) : 0)), launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, addend, st, fp));
         fused_ready = fp != nullptr;
         fused_rows = f.rows_written;
       }

@@ -168,3 +168,35 @@ def test_baseline_shape_properties(dtype):
     assert torch.allclose(permuted, full[perm], atol=1e-5 if dtype == "fp32" else 2e-3)
     _, loss, grads = _step(hip, img, meta, lab, DEV)
     assert loss == loss and all(torch.isfinite(v).all() for v in grads.values())
+
+
+def test_tab_transformer_block_and_wiring():
+    """TabTransformer metadata encoder on the HIP ops: the class against the reference fixture
+    (tests/golden/blocks.json), and the build-defined end-to-end wiring (parity unpinned in the reference,
+    whose own wiring raises -- SURVEY.md section 4) against the oracle."""
+    from models.tab_transformer import TabTransformer
+    from oracle.blocks import OracleTabTransformer
+    from oracle.detinit import det_tensor
+    gold = golden("blocks")["tab_transformer"]
+    tt = det_init_(TabTransformer([10] * 82, num_continuous=4, output_dim=85)).to(DEV)
+    tt.eval()
+    xc = (det_tensor("tt.cat", (3, 82)).abs() * 10).long().clamp_(0, 9)
+    xn = det_tensor("tt.num", (3, 4))
+    y = tt(xc.to(DEV), xn.to(DEV))
+    assert torch.allclose(y.double().cpu(), torch.tensor(gold["y"], dtype=torch.float64), rtol=1e-3, atol=1e-4)
+    # gradients vs the oracle class with identical weights
+    ref = det_init_(OracleTabTransformer([10] * 82, num_continuous=4, output_dim=85)); ref.eval()
+    y.square().sum().backward()
+    ref(xc, xn).square().sum().backward()
+    for (k, p), (_, q) in zip(tt.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and rel_err(p.grad, q.grad) < 2e-3, k
+    # end-to-end wiring: 82 categorical + 4 continuous columns in one float tensor
+    kw = dict(SMALL, text_model_name="tab-transformer", attention_mecanism="metablock", vocab_size=86)
+    cpu, hip = build_pair("fp32", **kw)
+    cpu.eval(); hip.eval()
+    img, _, _ = det_inputs(4, 32, 20, 6)
+    meta = torch.cat([xc.float(), xn], dim=1)
+    meta = torch.cat([meta, meta[:1]], dim=0)
+    with torch.no_grad():
+        a, b = cpu(img, meta), hip(img.to(DEV), meta.to(DEV)).cpu()
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), (a - b).abs().max()
