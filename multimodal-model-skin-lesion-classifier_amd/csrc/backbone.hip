@@ -71,6 +71,7 @@ struct SideStream {
   hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // main: buffer i holds a fresh dX
   hipEvent_t done[3] = {nullptr, nullptr, nullptr};    // side: the wgrad reading buffer i has finished
   bool done_valid[3] = {false, false, false};
+  hipEvent_t f_ready = nullptr, f_done = nullptr;      // forward: block input ready / downsample branch finished
   int init() {
     if (s) return MMSKIN_OK;
     int least = 0, greatest = 0;
@@ -84,6 +85,8 @@ struct SideStream {
       HIP_CHECK_RET(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming));
       HIP_CHECK_RET(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
     }
+    HIP_CHECK_RET(hipEventCreateWithFlags(&f_ready, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&f_done, hipEventDisableTiming));
     return MMSKIN_OK;
   }
 };
@@ -105,7 +108,7 @@ struct Plan {
   // workspace layout (bytes)
   size_t ws_bytes = 0;
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[7], off_slab, off_partial,
-      off_coefbwd, off_dwv, off_red, off_partial_b;
+      off_coefbwd, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
   size_t esz() const { return dtype == 1 ? 2 : 4; }
 };
@@ -229,6 +232,7 @@ int build_plan(Plan& p) {
   }
   p.stat_bytes = stat_rows_max * sizeof(float);
   p.off_stat = carve(cur, 2 * p.stat_bytes);
+  p.off_stat_b = carve(cur, 2 * p.stat_bytes);   // downsample branch (runs on the side stream)
   p.maxact_bytes = maxact * es;
   for (Unit& u : p.units) {
     u.coef_off = carve(cur, 4 * (size_t)u.s.Cout * sizeof(float));
@@ -253,6 +257,7 @@ int build_plan(Plan& p) {
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
+  p.off_red_b = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.ws_bytes = cur;
   return MMSKIN_OK;
 }
@@ -298,18 +303,25 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
   PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st));
 
-  auto bn_coeffs = [&](Unit& u, int stat_rows) -> int {
+  auto bn_coeffs_on = [&](Unit& u, int stat_rows, float* ssum, float* ssq, double* red, hipStream_t s2) -> int {
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
     const int C = u.s.Cout;
-    p.prof.begin(K_BN_FWD, st);
-    struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
+    p.prof.begin(K_BN_FWD, s2);
+    struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, s2};
     if (training)
-      return bn_finalize(stat_sum, stat_sq, stat_rows, C, (double)u.rows(), params + u.g_off, params + u.b_off, eps,
-                         mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C,
-                         reinterpret_cast<double*>(ws + p.off_red), st);
+      return bn_finalize(ssum, ssq, stat_rows, C, (double)u.rows(), params + u.g_off, params + u.b_off, eps,
+                         mom, buffers + u.rm_off, buffers + u.rv_off, coef, coef + C, coef + 2 * C, coef + 3 * C, red, s2);
     return bn_eval_coeffs(C, params + u.g_off, params + u.b_off, buffers + u.rm_off, buffers + u.rv_off, eps, coef,
-                          coef + C, st);
+                          coef + C, s2);
   };
+  auto bn_coeffs = [&](Unit& u, int stat_rows) -> int {
+    return bn_coeffs_on(u, stat_rows, stat_sum, stat_sq, reinterpret_cast<double*>(ws + p.off_red), st);
+  };
+  static const bool side_off_f = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
+  const bool use_side = !side_off_f && !p.prof.on;
+  if (use_side && (rc = p.side.init())) return rc;
+  float* stat_b_sum = reinterpret_cast<float*>(ws + p.off_stat_b);
+  float* stat_b_sq = reinterpret_cast<float*>(ws + p.off_stat_b + p.stat_bytes);
 
   // ---- stem
   Unit& u0 = p.units[0];
@@ -330,11 +342,23 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
     const T* cur = in;
     const int nu = (int)b.units.size();
     if (b.ds >= 0) {
+      // the downsample conv + its BN statistics only meet the main branch at the block's final BN-apply:
+      // they run on the side stream (own stat slab / reduction scratch) beside conv1..conv3
       Unit& d = p.units[b.ds];
-      PROF(K_CONV_FWD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)),
-           launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
-                              training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
-      if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
+      if (use_side) {
+        HIP_CHECK_RET(hipEventRecord(p.side.f_ready, st));
+        HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.f_ready, 0));
+        if ((rc = launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
+                                     training ? stat_b_sum : nullptr, training ? stat_b_sq : nullptr, p.side.s))) return rc;
+        if ((rc = bn_coeffs_on(d, conv_fwd_stat_rows(d.s), stat_b_sum, stat_b_sq,
+                               reinterpret_cast<double*>(ws + p.off_red_b), p.side.s))) return rc;
+        HIP_CHECK_RET(hipEventRecord(p.side.f_done, p.side.s));
+      } else {
+        PROF(K_CONV_FWD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)),
+             launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
+                                training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
+        if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
+      }
     }
     for (int i = 0; i < nu; ++i) {
       Unit& u = p.units[b.units[i]];
@@ -351,6 +375,7 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
       } else if (b.ds >= 0) {
         Unit& d = p.units[b.ds];
         float* dc = reinterpret_cast<float*>(ws + d.coef_off);
+        if (use_side) HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.f_done, 0));
         PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T),
              bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(), C, true, st));
       } else {
@@ -561,6 +586,7 @@ void mmskin_backbone_destroy(mmskin_backbone_t h) {
   if (h->plan.table_dev) (void)hipFree(h->plan.table_dev);
   if (h->plan.side.s) {
     for (int i = 0; i < 3; ++i) { (void)hipEventDestroy(h->plan.side.ready[i]); (void)hipEventDestroy(h->plan.side.done[i]); }
+    (void)hipEventDestroy(h->plan.side.f_ready); (void)hipEventDestroy(h->plan.side.f_done);
     (void)hipStreamDestroy(h->plan.side.s);
   }
   delete h;

@@ -655,34 +655,60 @@ int avgpool_bwd(const float* dfeat, int N, int HW, int C, T* dx, hipStream_t st)
 }
 
 // ------------------------------------------------------------------ weight staging
+// Destination-major: every thread produces 1 (stem) or 8 consecutive destination elements, so the bf16
+// stores are 16-byte coalesced and only the fp32 reads are strided (they hit L2: one layer's weights are
+// re-read by its neighbours).  blockIdx.y = layer; blockIdx.z = 0 forward layout, 1 dgrad layout.
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc* __restrict__ table,
                                                                 const float* __restrict__ params,
                                                                 T* __restrict__ wfwd, T* __restrict__ wdgrad,
                                                                 int need_dgrad) {
+  constexpr int EPC = DT<T>::EPC;
   const StageDesc d = table[blockIdx.y];
-  const int total = d.Cout * d.Cin * d.taps;
   const float* src = params + d.src_off;
-  for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
-    int o = i / (d.Cin * d.taps), rem = i - o * d.Cin * d.taps;
-    int c = rem / d.taps, t = rem - c * d.taps;
-    T v = from_f32<T>(src[i]);
-    if (d.stem) {
+  const int CT = d.Cin * d.taps;
+  if (d.stem) {
+    if (blockIdx.z) return;
+    const int total = d.Cout * d.Cin * d.taps;
+    for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+      int o = i / CT, rem = i - o * CT;
+      int c = rem / d.taps, t = rem - c * d.taps;
       int r = t / 7, s = t - r * 7;  // 7x7 taps, Cin = 3 -> wv[o][r][s*4 + c]
-      wfwd[d.fwd_off + ((size_t)o * 8 + r) * 32 + s * 4 + c] = v;
-    } else {
-      wfwd[d.fwd_off + ((size_t)o * d.taps + t) * d.Cin + c] = v;
-      if (need_dgrad) wdgrad[d.dgrad_off + ((size_t)c * d.taps + t) * d.Cout + o] = v;
+      wfwd[d.fwd_off + ((size_t)o * 8 + r) * 32 + s * 4 + c] = from_f32<T>(src[i]);
+    }
+    return;
+  }
+  if (blockIdx.z && !need_dgrad) return;
+  const int nchunks = d.Cout * CT / EPC;   // Cin and Cout are multiples of EPC for every GEMM conv
+  for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < nchunks; i += gridDim.x * EW_BLOCK) {
+    Chunk<T> v;
+    if (blockIdx.z == 0) {         // dst [o][t][c0..c0+EPC)
+      const int cpr = d.Cin / EPC;
+      int c0 = (i % cpr) * EPC, ot = i / cpr;
+      int t = ot % d.taps, o = ot / d.taps;
+      const float* s0 = src + ((size_t)o * d.Cin + c0) * d.taps + t;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = s0[(size_t)e * d.taps];
+      v.store(wfwd + d.fwd_off + (size_t)i * EPC);
+    } else {                       // dst [c][t][o0..o0+EPC)
+      const int opr = d.Cout / EPC;
+      int o0 = (i % opr) * EPC, ct = i / opr;
+      int t = ct % d.taps, c = ct / d.taps;
+      const float* s0 = src + ((size_t)o0 * d.Cin + c) * d.taps + t;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = s0[(size_t)e * CT];
+      v.store(wdgrad + d.dgrad_off + (size_t)i * EPC);
     }
   }
 }
 template <typename T>
 int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
                   T* wdgrad, bool need_dgrad, hipStream_t st) {
-  int gx = ceil_div(max_elems, EW_BLOCK * 8);
+  int gx = ceil_div(max_elems / DT<T>::EPC, EW_BLOCK * 2);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(stage_weights_kernel<T>, dim3(gx, nlayers), dim3(EW_BLOCK), 0, st, table_dev, params, wfwd,
-                     wdgrad, need_dgrad ? 1 : 0);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(stage_weights_kernel<T>, dim3(gx, nlayers, need_dgrad ? 2 : 1), dim3(EW_BLOCK), 0, st, table_dev,
+                     params, wfwd, wdgrad, need_dgrad ? 1 : 0);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -21,7 +21,7 @@ template <> struct WG<float> { static constexpr int MS = 16; };
 template <typename T, int PITCH> __device__ __forceinline__ int wg_swz(int row) {
   if constexpr (sizeof(T) == 4) {
     return (row & 1) << 2;
-  } else if constexpr (PITCH == 256) {
+  } else if constexpr (PITCH % 256 == 0) {
     return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
   } else {
     return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
@@ -272,7 +272,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps) {
   BO = (Cout % 128 == 0) ? 128 : 64;
   BKK = (Ktot % 128 == 0) ? 128 : 64;
-  MS *= (BO + BKK == 128) ? 4 : 2;   // rows per stage (MSF of the kernel)
+  // 256-wide cout tiles halve the re-reads of the gathered-input operand (env knob for A/B timing)
+  static const int bo256 = [] { const char* v = getenv("MMSKIN_WGRAD_BO256"); return v ? atoi(v) : 0; }();
+  if (bo256 && Cout % 256 == 0 && BKK == 128) BO = 256;
+  MS *= (BO == 256) ? 1 : ((BO + BKK == 128) ? 4 : 2);   // rows per stage (MSF of the kernel)
   int tiles = (Cout / BO) * (Ktot / BKK);
   // workgroups to aim for; swept 512..1536 on MI355X (1024 best).  An LDS-DMA staging variant of this
   // kernel was measured too and was 10 % slower than the register-staged loop kept here.
@@ -327,7 +330,8 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
   { const char* v = getenv("MMSKIN_WGRAD_ABLATE"); a.ablate = v ? atoi(v) : 0; }
   int rc;
-  if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 2>(a, st);
+  if (BO == 256) rc = launch_wg<T, 256, 128, 1>(a, st);
+  else if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 2>(a, st);
   else if (BO == 128) rc = launch_wg<T, 128, 64, 2>(a, st);
   else if (BKK == 128) rc = launch_wg<T, 64, 128, 2>(a, st);
   else rc = launch_wg<T, 64, 64, 4>(a, st);
