@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="force every rank onto this device (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,11 +94,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(device))   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
     from mmskin import _lib, dp
 
     model = build_model(device, args.dtype)
@@ -137,7 +143,7 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     roofline = None
     if rank == 0 and not args.no_roofline:

@@ -73,7 +73,7 @@ def _step(model, img, meta, lab, dev):
     out = model(img.to(dev), meta.to(dev))
     loss = nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS, device=dev))(out, lab.to(dev))
     loss.backward()
-    return out.detach().float().cpu(), float(loss), {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    return out.detach().float().cpu(), float(loss.detach()), {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}
 
 
 def _l2(a, b):
@@ -200,3 +200,60 @@ def test_tab_transformer_block_and_wiring():
     with torch.no_grad():
         a, b = cpu(img, meta), hip(img.to(DEV), meta.to(DEV)).cpu()
     assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("batch,hw", [(5, 96), (3, 160), (1, 224)])
+def test_ragged_batches_and_input_sizes(batch, hw):
+    """Odd batch sizes (last batch of an epoch), non-224 inputs and batch 1 (the API / XAI consumers) in
+    eval mode: partial row blocks in every kernel, odd spatial sizes in the strided layers."""
+    kw = dict(SMALL, cnn_model_name="resnet-50", common_dim=512, text_encoder_dim_output=512,
+              attention_mecanism="gfcam")
+    cpu, hip = build_pair("fp32", **kw)
+    cpu.eval(); hip.eval()
+    img, meta, _ = det_inputs(batch, hw, 20, 6)
+    with torch.no_grad():
+        a, b = cpu(img, meta), hip(img.to(DEV), meta.to(DEV)).cpu()
+    assert torch.allclose(a, b, rtol=1e-3, atol=1e-3), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("mode,expect_backbone_grads", [("frozen_weights", 0), ("last_layer_unfrozen_weights", 2),
+                                                        ("unfrozen_weights", 60)])
+def test_freeze_modes_train_step(mode, expect_backbone_grads):
+    """loadImageModelClassifier.py:15-35 freeze policy on the HIP path: train-mode BN still uses batch statistics
+    and updates running stats when frozen (train_pad_20.py:102), only the selected parameters get gradients."""
+    kw = dict(SMALL, cnn_model_name="resnet-18", common_dim=512, text_encoder_dim_output=512,
+              attention_mecanism="concatenation", unfreeze_weights=mode)
+    cpu, hip = build_pair("fp32", **kw)
+    img, meta, lab = det_inputs(8, 96, 20, 6)
+    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
+    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+    assert set(g_c) == set(g_h)
+    assert sum(k.startswith("image_encoder") for k in g_h) == expect_backbone_grads
+    assert float((out_c - out_h).abs().max()) < 1e-3 and abs(loss_c - loss_h) < 1e-4
+    for k in g_c:
+        if not k.startswith("image_encoder") or mode == "last_layer_unfrozen_weights":
+            assert rel_err(g_h[k], g_c[k]) < 5e-3, k
+    rv_c, rv_h = cpu.image_encoder.layer3[0].bn1.running_var, hip.image_encoder.layer3[0].bn1.running_var
+    assert rel_err(rv_h, rv_c) < 1e-4 and not torch.allclose(rv_c, torch.ones_like(rv_c))
+
+
+def test_checkpoint_round_trip_and_module_prefix():
+    """state_dict keys are an API: save from the HIP model, strip/add the DataParallel 'module.'
+    prefix like inference_all_folds.py:50-56, load with strict=False into a fresh model, same logits; the
+    early-stopping pattern copy.deepcopy(model.state_dict()) (early_stopping.py:61) keeps working."""
+    import copy
+    kw = dict(SMALL, cnn_model_name="resnet-18", common_dim=512, text_encoder_dim_output=512,
+              attention_mecanism="crossattention", device=DEV)
+    os.environ["MMSKIN_BACKBONE_DTYPE"] = "fp32"
+    a = det_init_(M.MultimodalModel(**kw)).to(DEV).eval()
+    best = copy.deepcopy(a.state_dict())
+    wrapped = {"module." + k: v for k, v in best.items()}
+    stripped = {k.replace("module.", "", 1): v for k, v in wrapped.items()}
+    stripped["some.unknown.key"] = torch.zeros(1)
+    b = M.MultimodalModel(**kw).to(DEV).eval()
+    res = b.load_state_dict(stripped, strict=False)
+    assert res.missing_keys == [] and res.unexpected_keys == ["some.unknown.key"]
+    img, meta, _ = det_inputs(4, 96, 20, 6)
+    with torch.no_grad():
+        assert torch.equal(a(img.to(DEV), meta.to(DEV)), b(img.to(DEV), meta.to(DEV)))
+    assert b.image_encoder._packed()
