@@ -40,6 +40,7 @@ struct Unit {  // conv + batch-norm
 struct Block {
   std::vector<int> units;
   int ds = -1;
+  size_t mask_off = 0;   // 1-bit ReLU mask of the block output (one byte per 16-byte chunk)
   size_t in_off;   // block input activation (bytes)
   int in_C, in_H, in_W;
 };
@@ -249,6 +250,8 @@ int build_plan(Plan& p) {
       u.y_off = carve(cur, u.rows() * u.s.Cout * es);
     }
     prev = p.units[b.units.back()].y_off;
+    Unit& bl = p.units[b.units.back()];
+    b.mask_off = carve(cur, bl.rows() * bl.s.Cout * es / 16);
   }
   for (int i = 0; i < 7; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
   p.off_slab = carve(cur, slab_max);
@@ -377,9 +380,11 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
         float* dc = reinterpret_cast<float*>(ws + d.coef_off);
         if (use_side) HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.f_done, 0));
         PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T),
-             bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(), C, true, st));
+             bn_apply<T>(x, reinterpret_cast<const T*>(ws + d.x_off), coef, coef + C, dc, dc + C, y, u.rows(), C, true, st,
+                         training ? ws + b.mask_off : nullptr));
       } else {
-        PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, in, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
+        PROF(K_BN_FWD, 0.0, 3.0 * u.rows() * C * sizeof(T),
+             bn_apply<T>(x, in, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st, training ? ws + b.mask_off : nullptr));
       }
       cur = y;
     }
@@ -527,7 +532,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if (bi > 0) {   // gin is the gradient of the previous block's output: fuse that block's final BN reduce
           Block& pb = p.blocks[bi - 1];
           Unit& pu = p.units[pb.units.back()];
-          f.mask_y = ws + pu.y_off; f.x = ws + pu.x_off; f.partial = partial;
+          f.mask_bits = ws + pb.mask_off; f.x = ws + pu.x_off; f.partial = partial;
           if (pb.ds >= 0) { f.x2 = ws + p.units[pb.ds].x_off; f.partial_b = partial_b; }
           fp = &f;
         }

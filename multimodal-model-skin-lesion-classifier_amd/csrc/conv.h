@@ -33,6 +33,7 @@ struct ConvGemmArgs {
   // ---- fused BatchNorm-backward prologue of the CONSUMER of `out` (dgrad launches only):
   // v = acc + addend; v *= mask; out = v; stat_sum += v; stat_sq += v*ep_x; stat_b_sq += v*ep_x2
   const void* ep_mask_y;   // mask = (ep_mask_y > 0)      (ReLU after a residual add: mask from the block output)
+  const uint8_t* ep_mask_bits;  // or: the same mask as one byte per 16-byte chunk (written by bn_apply)
   const void* ep_x;        // raw BN input x of the consumer unit (same shape as out)
   const float* ep_scale;   // with ep_shift: mask = (ep_x*scale + shift > 0)   (plain BN+ReLU)
   const float* ep_shift;
@@ -79,6 +80,7 @@ int conv_fwd_stat_rows(const ConvShape& s);
 // bn_bwd layout [row][2][C]; rows = conv_dgrad_partial_rows(s).
 struct DgradFuse {
   const void* mask_y = nullptr;
+  const uint8_t* mask_bits = nullptr;   // alternative to mask_y: 1 bit per element (1/16 of the bytes)
   const void* x = nullptr;
   const float* scale = nullptr;
   const float* shift = nullptr;

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
   const unsigned char* add_b = EPI ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
   const unsigned char* my_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
+  const uint8_t* mb_b = EPI ? p.ep_mask_bits : nullptr;
   const unsigned char* ex_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
   const unsigned char* ex2_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
   const bool mask_from_x = EPI && p.ep_scale != nullptr;
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
   for (int grp = 0; grp < NR; grp += EG) {
     u32x4_t q_ad[EG], q_my[EG], q_x[EG], q_x2[EG];
+    uint32_t q_mb[EG];
     size_t goffs[EG];
     bool valid[EG];
 #pragma unroll
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
       if constexpr (EPI) {
         q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
         q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
+        q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
         q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + goffs[k] : zp);
         q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
       }
@@ -287,6 +290,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         my.from_raw(q_my[k]);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v.v[e] = my.v[e] > 0.f ? v.v[e] : 0.f;
+      }
+      if (mb_b) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = ((q_mb[k] >> e) & 1u) ? v.v[e] : 0.f;
       }
       if (ex_b) {
         Chunk<T> xv;
@@ -377,7 +384,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   const char* abl = getenv("MMSKIN_CONV_ABLATE");   // timing experiments only
   a.ablate = abl ? atoi(abl) : 0;
   if (!simple && !a.ep_x) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
-  const bool epi = a.addend || a.ep_mask_y || a.ep_x;
+  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
@@ -445,7 +452,7 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   if (fuse) {
     ARG_CHECK(!(addend == din && addend != nullptr && s.stride != 1 && s.kh == 1),
               "conv_dgrad: epilogue fusion needs a launch that covers every output pixel");
-    a.ep_mask_y = fuse->mask_y; a.ep_x = fuse->x; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
+    a.ep_mask_y = fuse->mask_y; a.ep_mask_bits = fuse->mask_bits; a.ep_x = fuse->x; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
     a.ep_x2 = fuse->x2;
     a.stat_stride = 2 * s.Cin;
     a.stat_sum = fuse->partial; a.stat_sq = fuse->partial + s.Cin;

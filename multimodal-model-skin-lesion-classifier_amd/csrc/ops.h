@@ -20,7 +20,8 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
 // y = [relu](x*scale[c] + shift[c] [+ res | + res*rscale[c] + rshift[c]]);  rows*C elements
 template <typename T>
 int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
-             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st);
+             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st,
+             uint8_t* mask_bits = nullptr);   // optional: one byte per 16-byte chunk, bit e = (y[e] > 0)
 // Column partial sums of an arbitrary NHWC tensor (used where no conv epilogue produced them).
 template <typename T>
 int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq, int* nrows_out,

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ rscale,
                                                             const float* __restrict__ rshift, T* __restrict__ y,
-                                                            size_t nchunks, int CPR) {
+                                                            uint8_t* __restrict__ mask_bits, size_t nchunks, int CPR) {
   constexpr int EPC = DT<T>::EPC;
   for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
     int c0 = (int)(i % CPR) * EPC;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
     v.load(x + i * EPC);
     Chunk<T> r;
     if (RES) r.load(res + i * EPC);
+    uint32_t bits = 0;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float t = v.v[e] * scale[c0 + e] + shift[c0 + e];
@@ -243,20 +244,22 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
       if (RES == 2) t += r.v[e] * rscale[c0 + e] + rshift[c0 + e];
       if (RELU) t = fmaxf(t, 0.f);
       v.v[e] = t;
+      bits |= (from_f32<T>(t) != 0 && t > 0.f ? 1u : 0u) << e;   // bit = (stored y > 0)
     }
     v.store(y + i * EPC);
+    if (mask_bits) mask_bits[i] = (uint8_t)bits;   // one byte per 16-byte chunk: the ReLU mask for backward
   }
 }
 
 template <typename T>
 int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
-             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st) {
+             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st, uint8_t* mask_bits) {
   constexpr int EPC = DT<T>::EPC;
   ARG_CHECK(C % EPC == 0, "bn_apply: C=%d", C);
   size_t nch = rows * (C / EPC);
   int grid = ew_grid(nch);
   int mode = res ? (rscale ? 2 : 1) : 0;
-#define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, nch, C / EPC)
+#define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC)
   if (relu) { if (mode == 2) LAUNCH(true, 2); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 0); }
   else { if (mode == 2) LAUNCH(false, 2); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 0); }
 #undef LAUNCH
@@ -767,7 +770,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
 }
 
 #define INST(T)                                                                                               \
-  template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t); \
+  template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t, uint8_t*); \
   template int column_stats<T>(const T*, size_t, int, float*, float*, int*, hipStream_t);                       \
   template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, int*, hipStream_t); \
   template int bn_bwd_apply<T>(const T*, const T*, const T*, const float*, const float*, int, const float*, const float*, const float*, T*, T*, size_t, int, hipStream_t); \
