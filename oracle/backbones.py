@@ -88,6 +88,76 @@ class OracleResNet(nn.Module):
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth=32, bn_size=4):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=False)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=False)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        return self.conv2(self.relu2(self.norm2(self.conv1(self.relu1(self.norm1(x))))))
+
+
+class _DenseBlock(nn.Module):
+    def __init__(self, nlayers, cin, growth=32):
+        super().__init__()
+        for i in range(nlayers):
+            setattr(self, f"denselayer{i + 1}", _DenseLayer(cin + i * growth, growth))
+        self.nlayers = nlayers
+
+    def forward(self, x):
+        feats = [x]
+        for i in range(self.nlayers):
+            feats.append(getattr(self, f"denselayer{i + 1}")(torch.cat(feats, 1)))
+        return torch.cat(feats, 1)
+
+
+class _Transition(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(cin)
+        self.relu = nn.ReLU(inplace=False)
+        self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+        self.pool = nn.AvgPool2d(2, stride=2)
+
+
+class OracleDenseNet169(nn.Module):
+    """torchvision densenet169 layout (growth 32, blocks (6,12,32,32), bn_size 4, 64 init features);
+    forward = features -> relu -> adaptive_avg_pool2d(1) -> flatten -> classifier (Identity) => 1664.
+    PARITY UNPINNED against torchvision (absent); state_dict keys follow torchvision's."""
+
+    def __init__(self):
+        super().__init__()
+        from collections import OrderedDict
+        feats = OrderedDict()
+        feats["conv0"] = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        feats["norm0"] = nn.BatchNorm2d(64)
+        feats["relu0"] = nn.ReLU(inplace=False)
+        feats["pool0"] = nn.MaxPool2d(3, stride=2, padding=1)
+        c = 64
+        for bi, n in enumerate((6, 12, 32, 32), start=1):
+            feats[f"denseblock{bi}"] = _DenseBlock(n, c)
+            c += 32 * n
+            if bi < 4:
+                feats[f"transition{bi}"] = _Transition(c, c // 2)
+                c //= 2
+        feats["norm5"] = nn.BatchNorm2d(c)
+        self.features = nn.Sequential(feats)
+        self.classifier = nn.Identity()
+        self.num_features = c
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+    def forward(self, x):
+        f = F.relu(self.features(x))
+        return self.classifier(torch.flatten(F.adaptive_avg_pool2d(f, 1), 1))
+
+
 def custom_cnn(common_dim):
     """loadImageModelClassifier.py:50-60."""
     return nn.Sequential(
@@ -124,6 +194,15 @@ def build_image_encoder(name, common_dim, mode):
     elif name in RESNET_SPECS:
         net = OracleResNet(name)
         dim = net.num_features
+    elif name == "densenet169":
+        net = OracleDenseNet169()
+        dim = net.num_features
+        if mode == "partial":                        # loadImageModelClassifier.py:88-92
+            for p in net.parameters():
+                p.requires_grad = False
+            for p in net.features.denseblock4.parameters():
+                p.requires_grad = True
+            return net, dim
     else:
         raise ValueError(f"Backbone '{name}' não implementado.")
     apply_train_mode(net, mode)
