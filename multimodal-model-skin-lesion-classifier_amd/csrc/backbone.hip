@@ -7,23 +7,9 @@
 // backward.  Parameters stay fp32 masters in one flat buffer laid out in torchvision's
 // named_parameters() order; they are re-staged to the compute dtype (K-contiguous GEMM operands) at
 // the start of every forward.
-#include <stdlib.h>
-#include <string.h>
-
-#include <string>
-#include <vector>
-
-#include "conv.h"
-#include "ops.h"
+#include "plan.h"
 
 namespace {
-
-struct TensorInfo {
-  std::string name;
-  int64_t offset, numel;
-  int ndim;
-  int64_t shape[4];
-};
 
 struct Unit {  // conv + batch-norm
   ConvShape s;
@@ -45,89 +31,23 @@ struct Block {
   int in_C, in_H, in_W;
 };
 
-enum KClass { K_CONV_FWD = 0, K_CONV_DGRAD, K_WGRAD, K_BN_FWD, K_BN_BWD, K_STAGE, K_STEM_MISC, K_NCLASS };
-
-// Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
-// roofline).  Off by default: the timed region of a benchmark never pays for it.
-struct Profiler {
-  bool on = false;
-  std::vector<hipEvent_t> pool;
-  std::vector<int> cls;       // class of event pair i (events 2i, 2i+1)
-  size_t used = 0;
-  double flops[K_NCLASS] = {0};
-  double bytes[K_NCLASS] = {0};
-  hipEvent_t get() {
-    if (used == pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); pool.push_back(e); }
-    return pool[used++];
-  }
-  void begin(int c, hipStream_t st) { if (on) { cls.push_back(c); (void)hipEventRecord(get(), st); } }
-  void end(hipStream_t st) { if (on) (void)hipEventRecord(get(), st); }
-  void reset() { used = 0; cls.clear(); for (int i = 0; i < K_NCLASS; ++i) { flops[i] = 0; bytes[i] = 0; } }
-};
-
-// Weight-gradient GEMMs only feed the optimizer, so they run on a second HIP stream beside the
-// dgrad -> BN-backward chain of the main stream (fills launch tails and latency-bound phases).
-struct SideStream {
-  hipStream_t s = nullptr;
-  hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // main: buffer i holds a fresh dX
-  hipEvent_t done[3] = {nullptr, nullptr, nullptr};    // side: the wgrad reading buffer i has finished
-  bool done_valid[3] = {false, false, false};
-  hipEvent_t f_ready = nullptr, f_done = nullptr;      // forward: block input ready / downsample branch finished
-  int init() {
-    if (s) return MMSKIN_OK;
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const char* v = getenv("MMSKIN_SIDE_PRIORITY");   // "normal" (default) | "high" | "low": no measurable difference
-    int prio = 0;
-    if (v && !strcmp(v, "high")) prio = greatest;
-    if (v && !strcmp(v, "low")) prio = least;
-    HIP_CHECK_RET(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
-    for (int i = 0; i < 3; ++i) {
-      HIP_CHECK_RET(hipEventCreateWithFlags(&ready[i], hipEventDisableTiming));
-      HIP_CHECK_RET(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-    }
-    HIP_CHECK_RET(hipEventCreateWithFlags(&f_ready, hipEventDisableTiming));
-    HIP_CHECK_RET(hipEventCreateWithFlags(&f_done, hipEventDisableTiming));
-    return MMSKIN_OK;
-  }
-};
-
-struct Plan {
-  Profiler prof;
-  SideStream side;
-  int arch, N, H, W, dtype;
-  int feat_dim;
+struct Plan : PlanBase {
+  int arch;
   int Hp, Wp, OH0, OW0, PH, PW;
-  std::vector<TensorInfo> params, buffers;
-  int64_t param_numel = 0, buffer_numel = 0;
   std::vector<Unit> units;
   std::vector<Block> blocks;
-  StageDesc* table_dev = nullptr;
-  std::vector<StageDesc> table_host;
-  int max_stage_elems = 0;
   int64_t staged_elems = 0;
   // workspace layout (bytes)
-  size_t ws_bytes = 0;
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[7], off_slab, off_partial,
       off_coefbwd, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
-  size_t esz() const { return dtype == 1 ? 2 : 4; }
-};
 
-int64_t add_tensor(std::vector<TensorInfo>& v, int64_t& total, const std::string& name,
-                   std::initializer_list<int64_t> shape) {
-  TensorInfo t;
-  t.name = name;
-  t.offset = total;
-  t.ndim = (int)shape.size();
-  t.numel = 1;
-  int i = 0;
-  for (int64_t d : shape) { t.shape[i++] = d; t.numel *= d; }
-  for (; i < 4; ++i) t.shape[i] = 1;
-  total += t.numel;
-  v.push_back(t);
-  return t.offset;
-}
+  int forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
+              bool training, hipStream_t st) override;
+  int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) override;
+  int num_units() const override { return (int)units.size(); }
+  int unit_info(int index, std::string* name, int64_t* info12) const override;
+};
 
 int add_unit(Plan& p, const std::string& conv_name, const std::string& bn_name, ConvShape s) {
   Unit u;
@@ -139,12 +59,6 @@ int add_unit(Plan& p, const std::string& conv_name, const std::string& bn_name, 
   u.rv_off = add_tensor(p.buffers, p.buffer_numel, bn_name + ".running_var", {s.Cout});
   p.units.push_back(u);
   return (int)p.units.size() - 1;
-}
-
-size_t carve(size_t& cursor, size_t bytes) {
-  size_t o = cursor;
-  cursor = align_up(cursor + bytes, 256);
-  return o;
 }
 
 int build_plan(Plan& p) {
@@ -265,33 +179,6 @@ int build_plan(Plan& p) {
   return MMSKIN_OK;
 }
 
-#define PROF(cls_, flops_, bytes_, call_)                      \
-  do {                                                        \
-    p.prof.begin((cls_), st);                                 \
-    rc = (call_);                                             \
-    p.prof.end(st);                                           \
-    if (p.prof.on) { p.prof.flops[(cls_)] += (flops_); p.prof.bytes[(cls_)] += (bytes_); } \
-    if (rc) return rc;                                        \
-  } while (0)
-
-static inline double conv_flops(const ConvShape& s) {
-  return 2.0 * s.N * s.OH() * s.OW() * (double)s.Cout * s.Cin * s.kh * s.kw;
-}
-// algorithmic HBM bytes of one conv GEMM pass: input once, output once, weights once, plus `extra`
-// input-shaped tensors read by a fused dgrad epilogue (addend, mask source, BN inputs)
-static inline double conv_bytes(const ConvShape& s, size_t es, int extra_in_shaped = 0) {
-  double in = (double)s.N * s.H * s.W * s.Cin, out = (double)s.N * s.OH() * s.OW() * s.Cout;
-  return (in * (1 + extra_in_shaped) + out) * es + (double)s.Cout * s.Cin * s.kh * s.kw * es;
-}
-
-int ensure_table(Plan& p) {
-  if (p.table_dev) return MMSKIN_OK;
-  HIP_CHECK_RET(hipMalloc((void**)&p.table_dev, p.table_host.size() * sizeof(StageDesc)));
-  HIP_CHECK_RET(hipMemcpy(p.table_dev, p.table_host.data(), p.table_host.size() * sizeof(StageDesc),
-                          hipMemcpyHostToDevice));
-  return MMSKIN_OK;
-}
-
 template <typename T>
 int forward_impl(Plan& p, const float* image, const float* params, float* buffers, unsigned char* ws,
                  float* features, bool training, hipStream_t st) {
@@ -301,7 +188,7 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   float* stat_sum = reinterpret_cast<float*>(ws + p.off_stat);
   float* stat_sq = reinterpret_cast<float*>(ws + p.off_stat + p.stat_bytes);
   int rc;
-  if ((rc = ensure_table(p))) return rc;
+  if ((rc = p.ensure_table())) return rc;
   // stage weights (stem region needs zeros in its padding taps)
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
   PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st));
@@ -561,12 +448,40 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   return stem_wgrad_unpack(dwv, grads + u0.w_off, st);
 }
 
+int Plan::forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
+                  bool training, hipStream_t st) {
+  if (dtype == 1) return forward_impl<bf16_t>(*this, image, params, buffers, ws, features, training, st);
+  return forward_impl<float>(*this, image, params, buffers, ws, features, training, st);
+}
+int Plan::backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) {
+  if (dtype == 1) return backward_impl<bf16_t>(*this, dfeat, params, ws, grads, st);
+  return backward_impl<float>(*this, dfeat, params, ws, grads, st);
+}
+int Plan::unit_info(int index, std::string* name, int64_t* info12) const {
+  const Unit& u = units[index];
+  // the conv weight is the unit's first parameter; find its name through the param table
+  for (const TensorInfo& t : params)
+    if (t.offset == u.w_off && name) *name = t.name;
+  const int64_t v[12] = {(int64_t)u.x_off, (int64_t)u.y_off, (int64_t)u.coef_off, (int64_t)u.rows(), u.s.Cout,
+                         u.s.OH(), u.s.OW(), u.s.Cin, u.s.H, u.s.W, (int64_t)off_pool, (int64_t)off_scratch[0]};
+  for (int i = 0; i < 12; ++i) info12[i] = v[i];
+  return MMSKIN_OK;
+}
+
 }  // namespace
+
+PlanBase* make_resnet_plan(int arch, int N, int H, int W, int dtype, int* rc) {
+  Plan* p = new Plan();
+  p->arch = arch; p->N = N; p->H = H; p->W = W; p->dtype = dtype;
+  *rc = build_plan(*p);
+  if (*rc) { delete p; return nullptr; }
+  return p;
+}
 
 // ------------------------------------------------------------------------------------------ C ABI
 #include "../../include/mmskin.h"
 
-struct mmskin_backbone { Plan plan; };
+struct mmskin_backbone { PlanBase* plan = nullptr; };
 
 extern "C" {
 
@@ -575,35 +490,33 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   int a = 0;
   if (!strcmp(arch, "resnet-18")) a = 18;
   else if (!strcmp(arch, "resnet-50")) a = 50;
+  else if (!strcmp(arch, "densenet169")) a = 169;
   else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
   ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
   ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
+  int rc = MMSKIN_OK;
+  PlanBase* p = a == 169 ? make_densenet_plan(batch, height, width, dtype, &rc)
+                         : make_resnet_plan(a, batch, height, width, dtype, &rc);
+  if (!p) return rc ? rc : MMSKIN_ERR_ARG;
   mmskin_backbone* h = new mmskin_backbone();
-  h->plan.arch = a; h->plan.N = batch; h->plan.H = height; h->plan.W = width; h->plan.dtype = dtype;
-  int rc = build_plan(h->plan);
-  if (rc) { delete h; return rc; }
+  h->plan = p;
   *out = h;
   return MMSKIN_OK;
 }
 
 void mmskin_backbone_destroy(mmskin_backbone_t h) {
   if (!h) return;
-  if (h->plan.table_dev) (void)hipFree(h->plan.table_dev);
-  if (h->plan.side.s) {
-    for (int i = 0; i < 3; ++i) { (void)hipEventDestroy(h->plan.side.ready[i]); (void)hipEventDestroy(h->plan.side.done[i]); }
-    (void)hipEventDestroy(h->plan.side.f_ready); (void)hipEventDestroy(h->plan.side.f_done);
-    (void)hipStreamDestroy(h->plan.side.s);
-  }
+  delete h->plan;
   delete h;
 }
 
 int mmskin_backbone_num_tensors(mmskin_backbone_t h, int kind) {
-  return (int)(kind == 0 ? h->plan.params.size() : h->plan.buffers.size());
+  return (int)(kind == 0 ? h->plan->params.size() : h->plan->buffers.size());
 }
 
 int mmskin_backbone_tensor_info(mmskin_backbone_t h, int kind, int index, char* name, int name_cap,
                                 int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4) {
-  const std::vector<TensorInfo>& v = kind == 0 ? h->plan.params : h->plan.buffers;
+  const std::vector<TensorInfo>& v = kind == 0 ? h->plan->params : h->plan->buffers;
   ARG_CHECK(index >= 0 && index < (int)v.size(), "tensor_info: index %d out of range", index);
   const TensorInfo& t = v[index];
   if (name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
@@ -614,19 +527,19 @@ int mmskin_backbone_tensor_info(mmskin_backbone_t h, int kind, int index, char* 
   return MMSKIN_OK;
 }
 
-int64_t mmskin_backbone_param_numel(mmskin_backbone_t h) { return h->plan.param_numel; }
-int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h) { return h->plan.buffer_numel; }
-int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h) { return (int64_t)h->plan.ws_bytes; }
-int mmskin_backbone_feature_dim(mmskin_backbone_t h) { return h->plan.feat_dim; }
+int64_t mmskin_backbone_param_numel(mmskin_backbone_t h) { return h->plan->param_numel; }
+int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h) { return h->plan->buffer_numel; }
+int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h) { return (int64_t)h->plan->ws_bytes; }
+int mmskin_backbone_feature_dim(mmskin_backbone_t h) { return h->plan->feat_dim; }
 
 int mmskin_backbone_profile_enable(mmskin_backbone_t h, int on) {
-  h->plan.prof.on = on != 0;
-  h->plan.prof.reset();
+  h->plan->prof.on = on != 0;
+  h->plan->prof.reset();
   return MMSKIN_OK;
 }
 
 int mmskin_backbone_profile_read(mmskin_backbone_t h, double* ms7, double* flops7, double* bytes7, int64_t* launches7) {
-  Profiler& pr = h->plan.prof;
+  Profiler& pr = h->plan->prof;
   HIP_CHECK_RET(hipDeviceSynchronize());
   for (int c = 0; c < K_NCLASS; ++c) { ms7[c] = 0; flops7[c] = pr.flops[c]; bytes7[c] = pr.bytes[c]; launches7[c] = 0; }
   for (size_t i = 0; i < pr.cls.size(); ++i) {
@@ -639,37 +552,28 @@ int mmskin_backbone_profile_read(mmskin_backbone_t h, double* ms7, double* flops
   return MMSKIN_OK;
 }
 
-int mmskin_backbone_num_units(mmskin_backbone_t h) { return (int)h->plan.units.size(); }
+int mmskin_backbone_num_units(mmskin_backbone_t h) { return h->plan->num_units(); }
 
 int mmskin_backbone_unit_info(mmskin_backbone_t h, int index, char* name, int name_cap, int64_t* info12) {
-  ARG_CHECK(index >= 0 && index < (int)h->plan.units.size(), "unit_info: index %d out of range", index);
-  const Unit& u = h->plan.units[index];
-  // the conv weight is the unit's first parameter; find its name through the param table
-  for (const TensorInfo& t : h->plan.params)
-    if (t.offset == u.w_off && name && name_cap > 0) { strncpy(name, t.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
-  const int64_t v[12] = {(int64_t)u.x_off, (int64_t)u.y_off, (int64_t)u.coef_off, (int64_t)u.rows(), u.s.Cout,
-                         u.s.OH(), u.s.OW(), u.s.Cin, u.s.H, u.s.W, (int64_t)h->plan.off_pool,
-                         (int64_t)h->plan.off_scratch[0]};
-  for (int i = 0; i < 12; ++i) info12[i] = v[i];
+  ARG_CHECK(index >= 0 && index < h->plan->num_units(), "unit_info: index %d out of range", index);
+  std::string nm;
+  int rc = h->plan->unit_info(index, &nm, info12);
+  if (rc) return rc;
+  if (name && name_cap > 0) { strncpy(name, nm.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
   return MMSKIN_OK;
 }
 
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
                             void* workspace, float* features, int training, void* stream) {
   ARG_CHECK(h && image_nchw && params && buffers && workspace && features, "backbone_forward: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  if (h->plan.dtype == MMSKIN_BF16)
-    return forward_impl<bf16_t>(h->plan, image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0, st);
-  return forward_impl<float>(h->plan, image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0, st);
+  return h->plan->forward(image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0,
+                          (hipStream_t)stream);
 }
 
 int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,
                              float* param_grads, void* stream) {
   ARG_CHECK(h && dfeatures && params && workspace && param_grads, "backbone_backward: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  if (h->plan.dtype == MMSKIN_BF16)
-    return backward_impl<bf16_t>(h->plan, dfeatures, params, (unsigned char*)workspace, param_grads, st);
-  return backward_impl<float>(h->plan, dfeatures, params, (unsigned char*)workspace, param_grads, st);
+  return h->plan->backward(dfeatures, params, (unsigned char*)workspace, param_grads, (hipStream_t)stream);
 }
 
 }  // extern "C"

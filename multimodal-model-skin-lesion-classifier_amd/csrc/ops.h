@@ -70,12 +70,45 @@ struct StageDesc {
   int64_t dgrad_off; // element offset in the dgrad staging buffer    [Cin][taps][Cout]
   int Cout, Cin, taps;
   int stem;          // 1: conv1 7x7 -> virtual [64][8][32] (fwd only)
+  int Cout_pad, Cin_pad;   // staged dims (0 = same as Cout / Cin): extra rows / channels are zero
 };
 template <typename T>
 int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
                   T* wdgrad, bool need_dgrad, hipStream_t st);
 // dwv[64][8][32] -> OIHW [64][3][7][7]
 int stem_wgrad_unpack(const float* dwv, float* dw, hipStream_t st);
+
+// ---- channel-slice kernels for concatenating backbones (DenseNet): `cat` is [rows][pitch]
+// out[r][0..Cp) = c < C ? f(in[r*pitch + c]) : 0 with f = relu(x*scale[c]+shift[c]) when scale is given,
+// else identity.  `in` may point at a channel offset inside a row.
+template <typename T>
+int slice_pack(const T* in, int pitch, int C, int Cp, size_t rows, const float* scale, const float* shift, T* out,
+               hipStream_t st);
+// dst[r*pitch + c] = src[r*srcC + c] for c < C  (dst may point at a channel offset inside a row)
+template <typename T>
+int slice_scatter(const T* src, int srcC, int C, T* dst, int pitch, size_t rows, hipStream_t st);
+// dcat[r*pitch + c] (+)= cA[c]*dz[r*Cp + c] + cB[c]*x[r*pitch + c] + cC[c]   for c < C
+template <typename T>
+int slice_bn_bwd_accumulate(T* dcat, const T* x, int pitch, int C, const T* dz, int Cp, const float* cA,
+                            const float* cB, const float* cC, size_t rows, hipStream_t st);
+// column partial sums of x[r*pitch + c], c < C -> stat_sum/stat_sq [nrows][C]
+template <typename T>
+int slice_stats(const T* x, int pitch, int C, size_t rows, float* stat_sum, float* stat_sq, int* nrows_out,
+                hipStream_t st);
+// partial slabs [nrows][stride] (first C columns used) -> batch mean / biased variance
+int bn_table_finalize(const float* stat_sum, const float* stat_sq, int nrows, int stride, int C, double count,
+                      float* mean, float* var, double* scratch, hipStream_t st);
+// BatchNorm coefficients for a consumer of table channels [0, C): coef = scale|shift|mean|invstd|gamma,
+// each Cp long with zeros beyond C.  training: batch stats from the table (+ running-stat update);
+// eval: running stats.
+int bn_coef_from_table(const float* mean_tab, const float* var_tab, int C, int Cp, const float* gamma,
+                       const float* beta, float eps, float momentum, double count, float* running_mean,
+                       float* running_var, bool training, float* coef, hipStream_t st);
+// 2x2 stride-2 average pool of compact [N][H][W][C] into dst rows of `pitch` channels; and its backward
+template <typename T>
+int avgpool2_fwd(const T* x, int N, int H, int W, int C, T* dst, int pitch, hipStream_t st);
+template <typename T>
+int avgpool2_bwd(const T* dpool, int pitch, int N, int H, int W, int C, T* dx, hipStream_t st);
 
 // ---- layout converters used by the op-level C ABI (tests / small tensors)
 template <typename T>

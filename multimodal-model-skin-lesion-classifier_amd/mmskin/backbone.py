@@ -1,10 +1,11 @@
 """Image encoders on the HIP path.
 
-HipResNet mirrors torchvision's ResNet module tree (conv1/bn1/layerN.i.convK/bnK/downsample.{0,1})
+HipResNet / HipDenseNet mirror torchvision's module trees (conv1/bn1/layerN.i.convK/bnK/downsample.{0,1};
+features.denseblockB.denselayerL.{norm1,conv1,norm2,conv2}, features.transitionB.{norm,conv}, ...)
 so that `image_encoder.*` state_dict keys match checkpoints trained with the reference
-(loadImageModelClassifier.py:65-75 builds torchvision models).  All parameters are views
+(loadImageModelClassifier.py:65-92 builds torchvision models).  All parameters are views
 into ONE flat fp32 buffer and all BN running statistics into another; a whole forward (or
-backward) is a single C-ABI call into the plan executor (csrc/backbone.hip).
+backward) is a single C-ABI call into the plan executor (csrc/backbone.hip, csrc/densenet.hip).
 """
 import ctypes
 import os
@@ -118,39 +119,14 @@ class _BackboneFn(torch.autograd.Function):
         return (None, None, None) + (None,) * len(module._layout)
 
 
-class HipResNet(nn.Module):
-    def __init__(self, name, compute_dtype=None):
-        super().__init__()
-        if name not in RESNET_DEPTHS:
-            raise ValueError(f"Backbone '{name}' não implementado.")
-        self.arch = name
+class _FlatBackbone(nn.Module):
+    """Parameter arena + plan cache shared by the plan-executed backbones.  Sub-classes build the
+    torchvision-named module tree, set `self.arch`, then call `_init_flat()`."""
+
+    def _init_flat(self, compute_dtype):
         self.compute_dtype = (compute_dtype or default_compute_dtype()).lower()
         if self.compute_dtype not in _DTYPES:
             raise ValueError(f"unknown compute dtype {self.compute_dtype}")
-        bottleneck, depths = RESNET_DEPTHS[name]
-        exp = 4 if bottleneck else 1
-        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
-        self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
-        cin = 64
-        for li, (width, nblk) in enumerate(zip((64, 128, 256, 512), depths), start=1):
-            blocks = []
-            for b in range(nblk):
-                stride = 2 if (b == 0 and li > 1) else 1
-                cout = width * exp
-                ds = None
-                if stride != 1 or cin != cout:
-                    ds = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
-                blocks.append((_Bottleneck if bottleneck else _BasicBlock)(cin, width, stride, ds))
-                cin = cout
-            setattr(self, f"layer{li}", nn.Sequential(*blocks))
-        self.avgpool = nn.AdaptiveAvgPool2d(1)
-        self.fc = nn.Identity()
-        self.num_features = cin
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self._plans = {}
         self._flat_p = None
         self._flat_b = None
@@ -217,7 +193,11 @@ class HipResNet(nn.Module):
             mine = [(n, off, numel, shape) for (n, _), (off, numel, shape) in
                     zip(self.named_parameters(), self._layout)]
             if [(t[0], t[1], t[2]) for t in table] != [(t[0], t[1], t[2]) for t in mine]:
-                raise _lib.MMSkinError("HipResNet parameter layout disagrees with the C plan")
+                raise _lib.MMSkinError(f"{type(self).__name__} parameter layout disagrees with the C plan")
+            btable = plan.tensor_table(1)
+            bmine = [f"{n}.{k}" for n, _ in self._bn_buffers() for k in ("running_mean", "running_var")]
+            if [t[0] for t in btable] != bmine:
+                raise _lib.MMSkinError(f"{type(self).__name__} buffer layout disagrees with the C plan")
             if len(self._plans) >= 2:   # keep at most two shapes alive (train + ragged last batch)
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan
@@ -231,6 +211,101 @@ class HipResNet(nn.Module):
         if training:
             torch._foreach_add_([m.num_batches_tracked for _, m in self._bn_buffers()], 1)
         return feats
+
+
+class HipResNet(_FlatBackbone):
+    def __init__(self, name, compute_dtype=None):
+        super().__init__()
+        if name not in RESNET_DEPTHS:
+            raise ValueError(f"Backbone '{name}' não implementado.")
+        self.arch = name
+        bottleneck, depths = RESNET_DEPTHS[name]
+        exp = 4 if bottleneck else 1
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = 64
+        for li, (width, nblk) in enumerate(zip((64, 128, 256, 512), depths), start=1):
+            blocks = []
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 1) else 1
+                cout = width * exp
+                ds = None
+                if stride != 1 or cin != cout:
+                    ds = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
+                blocks.append((_Bottleneck if bottleneck else _BasicBlock)(cin, width, stride, ds))
+                cin = cout
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Identity()
+        self.num_features = cin
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._init_flat(compute_dtype)
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, cin, growth, bn_size):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(cin)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(cin, bn_size * growth, 1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth, growth, 3, padding=1, bias=False)
+
+
+class _DenseBlock(nn.Module):
+    def __init__(self, nlayers, cin, growth, bn_size):
+        super().__init__()
+        for i in range(nlayers):
+            setattr(self, f"denselayer{i + 1}", _DenseLayer(cin + i * growth, growth, bn_size))
+
+
+class _Transition(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(cin)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+        self.pool = nn.AvgPool2d(2, stride=2)
+
+
+class _Features(nn.Module):
+    pass
+
+
+class HipDenseNet(_FlatBackbone):
+    """torchvision densenet169 (growth 32, blocks 6/12/32/32, bn_size 4) with `classifier = Identity`
+    (loadImageModelClassifier.py:84-92) -> 1664 features."""
+
+    def __init__(self, name="densenet169", compute_dtype=None):
+        super().__init__()
+        if name != "densenet169":
+            raise ValueError(f"Backbone '{name}' não implementado.")
+        self.arch = name
+        growth, bn_size, c = 32, 4, 64
+        f = _Features()
+        f.conv0 = nn.Conv2d(3, c, 7, stride=2, padding=3, bias=False)
+        f.norm0 = nn.BatchNorm2d(c)
+        f.relu0 = nn.ReLU(inplace=True)
+        f.pool0 = nn.MaxPool2d(3, stride=2, padding=1)
+        for bi, n in enumerate((6, 12, 32, 32), start=1):
+            setattr(f, f"denseblock{bi}", _DenseBlock(n, c, growth, bn_size))
+            c += growth * n
+            if bi < 4:
+                setattr(f, f"transition{bi}", _Transition(c, c // 2))
+                c //= 2
+        f.norm5 = nn.BatchNorm2d(c)
+        self.features = f
+        self.classifier = nn.Identity()
+        self.num_features = c
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+        self._init_flat(compute_dtype)
 
 
 class HipCustomCNN(nn.Sequential):
