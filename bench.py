@@ -34,18 +34,45 @@ PEAK_F32_TFLOPS = 157.3
 FLOP_PER_IMAGE = 24.33e9    # conv fwd 8.174 + bwd 16.113 + head 0.039 GFLOP
 CLASS_NAMES = ["conv_fwd", "conv_dgrad", "wgrad", "bn_fwd", "bn_bwd", "stage_weights", "stem_misc"]
 
+# The headline line is configs[1]; configs[2] (DenseNet-169 + tab-transformer + metablock) is available
+# with --workload densenet169-metablock for the widened path.
+WORKLOADS = {
+    "resnet50-crossattention": {
+        "metric": "images/sec fwd+bwd, ResNet-50+crossattention bs=256",
+        "label": "ResNet-50 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+        "kw": dict(cnn_model_name="resnet-50", text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                   attention_mecanism="crossattention"),
+        "flop_per_image": FLOP_PER_IMAGE,
+    },
+    "densenet169-metablock": {
+        "metric": "images/sec fwd+bwd, DenseNet-169+tab-transformer+metablock bs=256",
+        "label": "DenseNet-169 + tab-transformer(82 cat + 4 cont) + metablock, 224x224, train step incl. Adam",
+        "kw": dict(cnn_model_name="densenet169", text_model_name="tab-transformer", common_dim=512, vocab_size=86,
+                   attention_mecanism="metablock"),
+        "flop_per_image": 3 * 6.72e9,   # torchvision densenet169: 3.36 GMAC forward; backward = 2x forward
+    },
+}
 
-def build_model(device, dtype):
+
+def make_meta(workload, batch, generator):
+    if workload == "densenet169-metablock":   # 82 categorical codes (cardinality 10) + 4 continuous columns
+        cat = torch.randint(0, 10, (batch, 82), generator=generator).float()
+        return torch.cat([cat, torch.randn(batch, 4, generator=generator)], dim=1)
+    return torch.randn(batch, 20, generator=generator)
+
+
+def build_model(device, dtype, workload="resnet50-crossattention", cls=None):
     os.environ["MMSKIN_BACKBONE_DTYPE"] = dtype
-    from models import multimodalIntraInterModal as M
+    if cls is None:
+        from models import multimodalIntraInterModal as M
+        cls = M.MultimodalModel
     torch.manual_seed(0)
-    model = M.MultimodalModel(num_classes=6, num_heads=8, device=device, cnn_model_name="resnet-50",
-                              text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
-                              unfreeze_weights="unfrozen_weights", attention_mecanism="crossattention", n=2)
+    model = cls(num_classes=6, num_heads=8, device=device, unfreeze_weights="unfrozen_weights", n=2,
+                **WORKLOADS[workload]["kw"])
     return model.to(device)
 
 
-def cpu_baseline(batch, seconds=12.0):
+def cpu_baseline(batch, seconds=12.0, workload="resnet50-crossattention"):
     """fwd+bwd of the CPU oracle (fp32, all host threads) on batches of `batch` until ~`seconds` elapsed."""
     from oracle.model import OracleMultimodalModel
     # the GPU box exposes every host core but a 1-GPU job owns a 16-core share: do not oversubscribe
@@ -55,11 +82,9 @@ def cpu_baseline(batch, seconds=12.0):
         avail = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(avail, 16)))
     torch.manual_seed(0)
-    model = OracleMultimodalModel(num_classes=6, num_heads=8, device="cpu", cnn_model_name="resnet-50",
-                                  text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
-                                  unfreeze_weights="unfrozen_weights", attention_mecanism="crossattention", n=2)
+    model = build_model("cpu", "fp32", workload, cls=OracleMultimodalModel)
     model.train()
-    img, meta = torch.randn(batch, 3, 224, 224), torch.randn(batch, 20)
+    img, meta = torch.randn(batch, 3, 224, 224), make_meta(workload, batch, None)
     lab = torch.randint(0, 6, (batch,))
     crit = nn.CrossEntropyLoss()
     def step():
@@ -83,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="resnet50-crossattention", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -105,14 +131,15 @@ def main():
             dist.init_process_group(args.backend)
     from mmskin import _lib, dp
 
-    model = build_model(device, args.dtype)
+    model = build_model(device, args.dtype, args.workload)
+    wl = WORKLOADS[args.workload]
     if world > 1:
         dp.broadcast_parameters(model)
     model.train()
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     image = torch.randn(B, 3, 224, 224, generator=g).to(device)
-    meta = torch.randn(B, 20, generator=g).to(device)
+    meta = make_meta(args.workload, B, g).to(device)
     label = torch.randint(0, 6, (B,), generator=g).to(device)
     crit = nn.CrossEntropyLoss(weight=torch.tensor([0.6, 1.7, 0.9, 1.2, 0.4, 2.1], device=device))
     opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)   # train_pad_20.py:54
@@ -191,20 +218,20 @@ def main():
         ips = world * B * args.steps / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         out = {
-            "metric": "images/sec fwd+bwd, ResNet-50+crossattention bs=256",
+            "metric": wl["metric"],
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "ResNet-50 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+            "config": {"workload": wl["label"],
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "weights": "random init (torchvision layout)", "unfreeze_weights": "unfrozen_weights"},
-            "step_tflops_per_gpu": round(ips / world * FLOP_PER_IMAGE / 1e12, 1),
-            "step_frac_of_peak": round(ips / world * FLOP_PER_IMAGE / 1e12 / peak, 4),
+            "step_tflops_per_gpu": round(ips / world * wl["flop_per_image"] / 1e12, 1),
+            "step_frac_of_peak": round(ips / world * wl["flop_per_image"] / 1e12 / peak, 4),
             "loss": round(loss_val, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(32)
+            out["cpu_baseline"] = cpu_baseline(32, workload=args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

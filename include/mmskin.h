@@ -132,11 +132,15 @@ int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int
 int mmskin_concat2_forward(const float* a, const float* b, float* out, int M, int Na, int Nb, void* stream);
 int mmskin_concat2_backward(const float* dout, float* da, float* db, int M, int Na, int Nb, void* stream);
 /* softmax attention for the metadata TabTransformer / generic L>1 attention:
- * q,k,v [B,H,L,Dh] -> o [B,H,L,Dh], probs p [B,H,L,L] saved for backward */
+ * q,k,v [B,H,L,Dh] -> o [B,H,L,Dh], softmax probs p [B,H,L,L] saved for backward.  drop_p > 0 applies
+ * training-mode dropout to the probabilities (nn.MultiheadAttention(dropout=...) inside
+ * nn.TransformerEncoderLayer, tab_transformer.py:20-27) with the counter-based generator of
+ * mmskin_dropout_forward: backward must be given the same (drop_p, seed, offset). */
 int mmskin_attention_forward(const float* q, const float* k, const float* v, float* o, float* p, int B, int H, int L,
-                             int Dh, void* stream);
+                             int Dh, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 int mmskin_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* p,
-                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, void* stream);
+                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, float drop_p,
+                              uint64_t seed, uint64_t offset, void* stream);
 /* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
                              void* stream);

@@ -283,10 +283,17 @@ __global__ void concat2_bwd_kernel(const float* dout, float* da, float* db, int 
 }
 
 // ------------------------------------------------------------------ small softmax attention
-// one workgroup per (b, h); L*L scores in LDS; one wave per score row for the softmax.
+// one workgroup per (b, h); L*L scores in LDS; one wave per score row for the softmax.  Training-mode
+// dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) inside the TabTransformer's
+// encoder layers) uses the same counter-based generator as the dropout op: element gi of call `offset`.
+__device__ __forceinline__ bool attn_keep(uint64_t seed, uint64_t offset, int64_t gi, float drop_p) {
+  uint64_t h = mix64(mix64(seed) ^ (offset + (uint64_t)gi));
+  return (float)(h >> 40) * (1.0f / 16777216.0f) >= drop_p;
+}
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ o,
-                                                            float* __restrict__ p, int L, int Dh) {
+                                                            float* __restrict__ p, int L, int Dh, float drop_p,
+                                                            uint64_t seed, uint64_t offset) {
   extern __shared__ float sc[];  // [L][L]
   const int64_t base = (int64_t)blockIdx.x * L * Dh;
   const float scale = 1.0f / sqrtf((float)Dh);
@@ -308,8 +315,10 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     const float inv = 1.f / sum;
     for (int j = lane; j < L; j += 64) {
       float pv = sc[i * L + j] * inv;
+      const int64_t gi = (int64_t)blockIdx.x * L * L + i * L + j;
+      p[gi] = pv;   // the pure softmax is what backward needs; the dropout mask is recomputed there
+      if (drop_p > 0.f) pv = attn_keep(seed, offset, gi, drop_p) ? pv * (1.f / (1.f - drop_p)) : 0.f;
       sc[i * L + j] = pv;
-      p[(int64_t)blockIdx.x * L * L + i * L + j] = pv;
     }
   }
   __syncthreads();
@@ -324,22 +333,28 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
                                                             const float* __restrict__ k, const float* __restrict__ v,
                                                             const float* __restrict__ p, float* __restrict__ dq,
                                                             float* __restrict__ dk, float* __restrict__ dv, int L,
-                                                            int Dh) {
+                                                            int Dh, float drop_p, uint64_t seed, uint64_t offset) {
   extern __shared__ float ds[];  // [L][L]
   const int64_t base = (int64_t)blockIdx.x * L * Dh;
-  const float* pp = p + (int64_t)blockIdx.x * L * L;
+  const int64_t pbase = (int64_t)blockIdx.x * L * L;
+  const float* pp = p + pbase;
   const float scale = 1.0f / sqrtf((float)Dh);
-  for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {  // dV = P^T dO
+  const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int idx = threadIdx.x; idx < L * L; idx += 256)   // dropout factor of every probability
+    ds[idx] = (drop_p > 0.f && !attn_keep(seed, offset, pbase + idx, drop_p)) ? 0.f : dscale;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {  // dV = P'^T dO,  P' = P * factor
     int j = idx / Dh, d = idx - j * Dh;
     float s = 0.f;
-    for (int i = 0; i < L; ++i) s += pp[i * L + j] * dO[base + i * Dh + d];
+    for (int i = 0; i < L; ++i) s += pp[i * L + j] * ds[i * L + j] * dO[base + i * Dh + d];
     dv[base + idx] = s;
   }
-  for (int idx = threadIdx.x; idx < L * L; idx += 256) {  // dP
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < L * L; idx += 256) {  // dP = (dO V^T) * factor
     int i = idx / L, j = idx - i * L;
     float s = 0.f;
     for (int d = 0; d < Dh; ++d) s += dO[base + i * Dh + d] * v[base + j * Dh + d];
-    ds[idx] = s;
+    ds[idx] *= s;
   }
   __syncthreads();
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -575,18 +590,20 @@ int mmskin_concat2_backward(const float* dout, float* da, float* db, int M, int 
 }
 
 int mmskin_attention_forward(const float* q, const float* k, const float* v, float* o, float* p, int B, int H, int L,
-                             int Dh, void* stream) {
+                             int Dh, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
   ARG_CHECK(q && k && v && o && p && B > 0 && H > 0 && L > 0 && Dh > 0, "attention_forward: bad argument");
+  ARG_CHECK(drop_p >= 0.f && drop_p < 1.f, "attention_forward: dropout %f", drop_p);
   ARG_CHECK((size_t)L * L * 4 <= 64 * 1024, "attention_forward: L=%d too long for the small-attention kernel", L);
-  hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), q, k, v, o, p, L, Dh);
+  hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), q, k, v, o, p, L, Dh, drop_p, seed, offset);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 int mmskin_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* p,
-                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, void* stream) {
+                              float* dq, float* dk, float* dv, int B, int H, int L, int Dh, float drop_p,
+                              uint64_t seed, uint64_t offset, void* stream) {
   ARG_CHECK(dO && q && k && v && p && dq && dk && dv, "attention_backward: null argument");
   ARG_CHECK((size_t)L * L * 4 <= 64 * 1024, "attention_backward: L=%d too long", L);
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), dO, q, k, v, p, dq, dk, dv, L, Dh);
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), dO, q, k, v, p, dq, dk, dv, L, Dh, drop_p, seed, offset);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -65,8 +65,8 @@ _SIGNATURES = {
     "mmskin_dropout_backward": (_i, [_P] * 3 + [_i64, _f, _P]),
     "mmskin_concat2_forward": (_i, [_P] * 3 + [_i] * 3 + [_P]),
     "mmskin_concat2_backward": (_i, [_P] * 3 + [_i] * 3 + [_P]),
-    "mmskin_attention_forward": (_i, [_P] * 5 + [_i] * 4 + [_P]),
-    "mmskin_attention_backward": (_i, [_P] * 8 + [_i] * 4 + [_P]),
+    "mmskin_attention_forward": (_i, [_P] * 5 + [_i] * 4 + [_f, _u64, _u64, _P]),
+    "mmskin_attention_backward": (_i, [_P] * 8 + [_i] * 4 + [_f, _u64, _u64, _P]),
     "mmskin_embedding_forward": (_i, [_P] * 3 + [_i] * 4 + [_P]),
     "mmskin_embedding_backward": (_i, [_P] * 3 + [_i] * 4 + [_P]),
     "mmskin_direct_conv2d_forward": (_i, [_P] * 4 + [_i] * 10 + [_P]),

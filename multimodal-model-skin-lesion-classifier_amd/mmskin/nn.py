@@ -80,7 +80,7 @@ class HipMultiheadAttention(nn.MultiheadAttention):
             k = ops.linear(key.reshape(Lk * B, D), W[D:2 * D], Bv[D:2 * D] if Bv is not None else None)
             v = ops.linear(value.reshape(Lk * B, D), W[2 * D:], Bv[2 * D:] if Bv is not None else None)
             split = lambda t, L: t.reshape(L, B, H, D // H).permute(1, 2, 0, 3).contiguous()
-            a = ops.attention(split(q, Lq), split(k, Lk), split(v, Lk))       # [B,H,Lq,Dh]
+            a = ops.attention(split(q, Lq), split(k, Lk), split(v, Lk), self.dropout, self.training)   # [B,H,Lq,Dh]
             a = a.permute(2, 0, 1, 3).reshape(Lq * B, D)
             o = ops.linear(a, self.out_proj.weight, self.out_proj.bias).reshape(Lq, B, D)
         if self.batch_first:

@@ -229,17 +229,19 @@ concat2 = Concat2Fn.apply
 
 
 class AttentionFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(Dh)) v on [B, H, L, Dh] tensors."""
+    """softmax(q k^T / sqrt(Dh)) v on [B, H, L, Dh] tensors; optional dropout on the probabilities."""
 
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, drop_p, seed, offset):
         _need_gpu(q, "attention")
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
         B, H, L, Dh = q.shape
         o = torch.empty_like(q)
         p = torch.empty((B, H, L, L), device=q.device, dtype=torch.float32)
-        call("mmskin_attention_forward", ptr(q), ptr(k), ptr(v), ptr(o), ptr(p), B, H, L, Dh, stream())
+        call("mmskin_attention_forward", ptr(q), ptr(k), ptr(v), ptr(o), ptr(p), B, H, L, Dh, float(drop_p), int(seed),
+             int(offset), stream())
         ctx.save_for_backward(q, k, v, p)
+        ctx.rng = (float(drop_p), int(seed), int(offset))
         return o
 
     @staticmethod
@@ -249,11 +251,18 @@ class AttentionFn(torch.autograd.Function):
         dO = _f32c(dO)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         call("mmskin_attention_backward", ptr(dO), ptr(q), ptr(k), ptr(v), ptr(p), ptr(dq), ptr(dk), ptr(dv), B, H, L,
-             Dh, stream())
-        return dq, dk, dv
+             Dh, *ctx.rng, stream())
+        return dq, dk, dv, None, None, None
 
 
-attention = AttentionFn.apply
+def attention(q, k, v, dropout_p=0.0, training=False):
+    if not training or dropout_p <= 0.0:
+        return AttentionFn.apply(q, k, v, 0.0, 0, 0)
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    B, H, L, _ = q.shape
+    _dropout_counter[0] += B * H * L * L
+    return AttentionFn.apply(q, k, v, dropout_p, seed, _dropout_counter[0])
+
 
 
 class EmbeddingFn(torch.autograd.Function):

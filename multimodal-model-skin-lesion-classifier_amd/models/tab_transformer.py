@@ -44,7 +44,7 @@ class TabTransformer(nn.Module):
         sa = layer.self_attn
         qkv = ops.linear(x.reshape(B * L, E), sa.in_proj_weight, sa.in_proj_bias)        # [B*L, 3E]
         qkv = qkv.reshape(B, L, 3, H, E // H).permute(2, 0, 3, 1, 4).contiguous()       # [3,B,H,L,Dh]
-        a = ops.attention(qkv[0], qkv[1], qkv[2]).permute(0, 2, 1, 3).reshape(B * L, E)
+        a = ops.attention(qkv[0], qkv[1], qkv[2], sa.dropout, self.training).permute(0, 2, 1, 3).reshape(B * L, E)
         a = ops.linear(a, sa.out_proj.weight, sa.out_proj.bias)
         a = ops.dropout(a, self.drop_p, self.training)
         x2 = ops.layernorm((x.reshape(B * L, E) + a), layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)

@@ -21,8 +21,11 @@ def disable_dropout(model):
     for m in model.modules():
         if isinstance(m, nn.Dropout):
             m.p = 0.0
-        if hasattr(m, "dropout_p"):
-            m.dropout_p = 0.0
+        if isinstance(m, nn.MultiheadAttention):
+            m.dropout = 0.0                      # attention-probability dropout (a float, not a module)
+        for attr in ("dropout_p", "drop_p"):
+            if hasattr(m, attr):
+                setattr(m, attr, 0.0)
 
 
 def summarize(t):

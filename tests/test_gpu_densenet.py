@@ -125,7 +125,7 @@ def test_densenet_config3_model_fp32():
         out = m(img.to(dev), meta.to(dev))
         loss = nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS, device=dev))(out, lab.to(dev))
         loss.backward()
-        res[name] = (out.detach().cpu(), float(loss), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
+        res[name] = (out.detach().cpu(), float(loss.detach()), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
     assert (res["cpu"][0] - res["hip"][0]).abs().max() < 1e-3                  # north_star: 1e-3 fp32
     assert abs(res["cpu"][1] - res["hip"][1]) < 1e-4
     assert set(res["cpu"][2]) == set(res["hip"][2])

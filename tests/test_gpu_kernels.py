@@ -243,6 +243,37 @@ def test_attention(B, H, L, Dh):
     _chk(out, ref, 1e-4); _chk(qd.grad, qr.grad, 1e-4); _chk(kd.grad, kr.grad, 1e-4); _chk(vd.grad, vr.grad, 1e-4)
 
 
+def test_attention_probability_dropout():
+    """Training-mode dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) inside the
+    TabTransformer encoder).  RNG streams cannot match torch's, so the check is structural: with V = identity the
+    output IS the dropped probability matrix, which gives the mask; forward and backward must then equal the
+    torch formula softmax(qk^T/sqrt(d)) * mask / (1-p) @ v for that mask, and the keep rate must be ~1-p."""
+    B, H, L, p = 4, 4, 32, 0.3
+    g = torch.Generator().manual_seed(5)
+    q, k = (torch.randn(B, H, L, L, generator=g) for _ in range(2))
+    eye = torch.eye(L).expand(B, H, L, L).contiguous()
+    torch.manual_seed(77)
+    cnt0 = ops._dropout_counter[0]
+    probe = ops.attention(q.to(DEV), k.to(DEV), eye.to(DEV), p, True).cpu()          # = P * mask / (1-p)
+    mask = (probe != 0).float()
+    soft = torch.softmax(q @ k.transpose(-1, -2) / L ** 0.5, dim=-1)
+    _chk(probe, soft * mask / (1 - p), 1e-4)
+    assert abs(float(mask.mean()) - (1 - p)) < 0.02
+    # same (seed, offset) -> same mask: rerun with a real V and compare with autograd through the torch formula
+    ops._dropout_counter[0] = cnt0
+    v = torch.randn(B, H, L, L, generator=g)
+    dO = torch.randn(B, H, L, L, generator=g)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) / L ** 0.5, dim=-1) * mask / (1 - p)) @ vr
+    ref.backward(dO)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention(qd, kd, vd, p, True)
+    out.backward(dO.to(DEV))
+    _chk(out, ref, 1e-4); _chk(qd.grad, qr.grad, 1e-4); _chk(kd.grad, kr.grad, 1e-4); _chk(vd.grad, vr.grad, 1e-4)
+    # eval mode / p = 0: no dropout
+    _chk(ops.attention(qd, kd, vd, p, False), soft @ v, 1e-4)
+
+
 def test_custom_cnn_pieces():
     g = torch.Generator().manual_seed(11)
     x = torch.randn(3, 3, 32, 32, generator=g)
