@@ -106,10 +106,12 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
 int stem_conv_stat_rows(int N, int OH, int OW);
 
 size_t conv_wgrad_slab_bytes(const ConvShape& s);
-// dw_kc: fp32 [Cout][kh*kw][Cin] (tap-major, channel-minor), reduced over the split slabs.
+// dw: fp32 OIHW [Cout][Cin][kh][kw], reduced over the split slabs.  cout_valid / cin_valid (0 = all): when the
+// GEMM operands carry zero padding (s.Cout / s.Cin rounded up to 64), dw is the UNPADDED
+// [cout_valid][cin_valid][kh][kw] tensor and the padded rows / channels are dropped.
 template <typename T>
-int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw_kc,
-                      hipStream_t st);
+int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw,
+                      hipStream_t st, int cout_valid = 0, int cin_valid = 0);
 size_t stem_wgrad_slab_bytes(int N, int OH, int OW);
 template <typename T>
 int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout, const T* img4,

@@ -54,7 +54,7 @@ struct DensePlan : PlanBase {
   std::vector<DBlock> blocks;
   DTrans trans[3];
   BNRef n5; size_t coef5_off, y5_off;
-  size_t off_wf, off_wd, off_stat, off_partial, off_coefbwd, off_dwtmp, off_dgtmp, off_dwv, off_red, off_slab;
+  size_t off_wf, off_wd, off_stat, off_partial, off_coefbwd, off_dwv, off_red, off_slab;
   size_t off_sB, off_sU, off_sA, off_sX, off_sZ, off_sC;
   size_t stat_bytes = 0;
 
@@ -156,7 +156,7 @@ int build_dense_plan(DensePlan& p) {
   size_t stat_floats = (size_t)stem_conv_stat_rows(p.N, p.OH0, p.OW0) * 64;
   size_t partial_bytes = (size_t)bn_bwd_partial_rows(rows0, 64) * 2 * 64 * sizeof(float);
   size_t slab = stem_wgrad_slab_bytes(p.N, p.OH0, p.OW0);
-  size_t small_elems = 0, big_elems = rows0 * 64, dwtmp = (size_t)G_PAD * BOTTLE * 9;
+  size_t small_elems = 0, big_elems = rows0 * 64;
   int maxC = BOTTLE;
   auto need_stat = [&](size_t floats) { if (floats > stat_floats) stat_floats = floats; };
   auto need_partial = [&](size_t rows, int C) {
@@ -187,7 +187,6 @@ int build_dense_plan(DensePlan& p) {
       need_partial(b.rows, BOTTLE);
       need_slab(c1); need_slab(c2);
       if (b.rows * l.Cp > big_elems) big_elems = b.rows * l.Cp;
-      if ((size_t)BOTTLE * l.Cp > dwtmp) dwtmp = (size_t)BOTTLE * l.Cp;
     }
     if (b.rows * b.Ctot > big_elems) big_elems = b.rows * b.Ctot;
     if (bi < 3) {
@@ -208,8 +207,6 @@ int build_dense_plan(DensePlan& p) {
   p.off_stat = carve(cur, 2 * p.stat_bytes);
   p.off_partial = carve(cur, partial_bytes);
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
-  p.off_dwtmp = carve(cur, dwtmp * sizeof(float));
-  p.off_dgtmp = carve(cur, 2 * (size_t)maxC * sizeof(float));
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.off_slab = carve(cur, slab);
@@ -345,8 +342,6 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
   float* slab = reinterpret_cast<float*>(ws + p.off_slab);
   float* partial = reinterpret_cast<float*>(ws + p.off_partial);
   float* cA = reinterpret_cast<float*>(ws + p.off_coefbwd);
-  float* dwtmp = reinterpret_cast<float*>(ws + p.off_dwtmp);
-  float* dgtmp = reinterpret_cast<float*>(ws + p.off_dgtmp);
   double* red = reinterpret_cast<double*>(ws + p.off_red);
   T* sB = reinterpret_cast<T*>(ws + p.off_sB);
   T* sU = reinterpret_cast<T*>(ws + p.off_sU);
@@ -392,8 +387,7 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       // gradient of this layer's 32 output channels, padded to the GEMM's 64
       PROF(K_BN_BWD, 0.0, 2.0 * b.rows * GROWTH * sizeof(T), slice_pack<T>(dcat + l.Cin, b.Ctot, GROWTH, G_PAD, b.rows, nullptr, nullptr, sB, st));
       // conv2: weight gradient (first 32 rows are real) and data gradient with norm2's mask + sums fused
-      PROF(K_WGRAD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T)), launch_conv_wgrad<T>(c2, sB, u, slab, dwtmp, st));
-      HIP_CHECK_RET(hipMemcpyAsync(grads + l.w2_off, dwtmp, (size_t)GROWTH * BOTTLE * 9 * sizeof(float), hipMemcpyDeviceToDevice, st));
+      PROF(K_WGRAD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T)), launch_conv_wgrad<T>(c2, sB, u, slab, grads + l.w2_off, st, GROWTH, 0));
       DgradFuse f2;
       f2.x = a; f2.scale = k2; f2.shift = k2 + BOTTLE; f2.partial = partial;
       PROF(K_CONV_DGRAD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T), 1), launch_conv_dgrad<T>(c2, sB, wd + l.wd2, sU, (const T*)nullptr, st, &f2));
@@ -407,14 +401,8 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
         if (p.prof.on) p.prof.bytes[K_BN_BWD] += 3.0 * b.rows * BOTTLE * sizeof(T);
         if (rc) return rc;
       }
-      // conv1: weight gradient [128][Cp] -> [128][Cin]
-      if (l.Cp == l.Cin) {
-        PROF(K_WGRAD, conv_flops(c1), conv_bytes(c1, sizeof(T)), launch_conv_wgrad<T>(c1, sA, t, slab, grads + l.w1_off, st));
-      } else {
-        PROF(K_WGRAD, conv_flops(c1), conv_bytes(c1, sizeof(T)), launch_conv_wgrad<T>(c1, sA, t, slab, dwtmp, st));
-        HIP_CHECK_RET(hipMemcpy2DAsync(grads + l.w1_off, (size_t)l.Cin * sizeof(float), dwtmp, (size_t)l.Cp * sizeof(float),
-                                       (size_t)l.Cin * sizeof(float), BOTTLE, hipMemcpyDeviceToDevice, st));
-      }
+      // conv1: weight gradient, padded input channels dropped by the reduction
+      PROF(K_WGRAD, conv_flops(c1), conv_bytes(c1, sizeof(T)), launch_conv_wgrad<T>(c1, sA, t, slab, grads + l.w1_off, st, 0, l.Cin));
       // conv1 data gradient with norm1's mask + sums fused (needs the raw prefix as a compact tensor)
       PROF(K_BN_BWD, 0.0, (double)b.rows * (l.Cin + l.Cp) * sizeof(T), slice_pack<T>(cat, b.Ctot, l.Cin, l.Cp, b.rows, nullptr, nullptr, sX, st));
       DgradFuse f1;
@@ -423,14 +411,12 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       {
         float* cB = cA + l.Cp; float* cC = cA + 2 * l.Cp;
         p.prof.begin(K_BN_BWD, st);
-        rc = bn_bwd_finalize(partial, f1.rows_written, l.Cp, count, k1 + 4 * l.Cp, k1 + 2 * l.Cp, k1 + 3 * l.Cp, dgtmp, dgtmp + l.Cp,
-                             cA, cB, cC, red, st);
+        rc = bn_bwd_finalize(partial, f1.rows_written, l.Cp, count, k1 + 4 * l.Cp, k1 + 2 * l.Cp, k1 + 3 * l.Cp,
+                             grads + l.n1.g_off, grads + l.n1.b_off, cA, cB, cC, red, st, l.Cin);
         if (!rc) rc = slice_bn_bwd_accumulate<T>(dcat, cat, b.Ctot, l.Cin, sZ, l.Cp, cA, cB, cC, b.rows, st);
         p.prof.end(st);
         if (p.prof.on) p.prof.bytes[K_BN_BWD] += 4.0 * b.rows * l.Cin * sizeof(T);
         if (rc) return rc;
-        HIP_CHECK_RET(hipMemcpyAsync(grads + l.n1.g_off, dgtmp, (size_t)l.Cin * sizeof(float), hipMemcpyDeviceToDevice, st));
-        HIP_CHECK_RET(hipMemcpyAsync(grads + l.n1.b_off, dgtmp + l.Cp, (size_t)l.Cin * sizeof(float), hipMemcpyDeviceToDevice, st));
       }
     }
     if (bi > 0) {

@@ -8,6 +8,29 @@
 
 #define ST(s) ((hipStream_t)(s))
 
+// Library-owned scratch for split reductions (split-K partial tiles, column-sum partial rows).  The head's
+// C entry points carry no workspace argument (they mirror nn.Linear / nn.LayerNorm call sites), so the
+// buffer is allocated lazily and only ever grows; every user runs on the caller's stream, in order.
+static float* head_scratch(size_t bytes) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (bytes > cap) {
+    if (buf) (void)hipFree(buf);   // implicit device sync: no kernel still reads the old buffer
+    size_t want = bytes < (size_t)(8 << 20) ? (size_t)(8 << 20) : bytes;
+    if (hipMalloc((void**)&buf, want) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
+    cap = want;
+  }
+  return buf;
+}
+// out[i] = sum_s part[s*n + i]
+__global__ void split_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) t += part[(int64_t)s2 * n + i];
+    out[i] = t;
+  }
+}
+
 // ------------------------------------------------------------------ generic strided f32 GEMM
 // C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]) ; A(m,k) = a[m*sam + k*sak] ; B(n,k) = b[n*sbn + k*sbk]
 // The head's GEMMs have M = batch (256) and N, K <= 2048: tiny for a 256-CU chip, so the kernel is built
@@ -24,9 +47,17 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ c, const float* __restrict__ bias, int M,
                                                        int N, int K, int64_t sam, int64_t sak, int64_t sbn,
-                                                       int64_t sbk, int64_t ldc, int relu) {
+                                                       int64_t sbk, int64_t ldc, int relu, int kchunk) {
   __shared__ float As[LG_BK * LG_PM];
   __shared__ float Bs[LG_BK * LG_PM];
+  // split-K (kchunk > 0): slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and writes its own M x ldc
+  // partial matrix; the caller sums the slices.  Used by the weight-gradient GEMMs whose K is batch*tokens.
+  if (kchunk > 0) {
+    const int kb = blockIdx.z * kchunk;
+    a += (int64_t)kb * sak; b += (int64_t)kb * sbk;
+    c += (int64_t)blockIdx.z * M * ldc;
+    K = min(kchunk, K - kb);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int m0 = blockIdx.y * LG_T, n0 = blockIdx.x * LG_T;
   const int wm = wid >> 1, wn = wid & 1;
@@ -83,13 +114,33 @@ static int gemm_f32(const float* a, const float* b, float* c, const float* bias,
   if (M <= 0 || N <= 0) return MMSKIN_OK;
   dim3 grid(ceil_div(N, LG_T), ceil_div(M, LG_T));
   const bool akc = sak == 1, bkc = sbk == 1;
-#define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, c, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu)
+  // few output tiles but a long contraction (dW = dY^T X over batch*tokens rows): split K over blockIdx.z
+  int S = 1, kchunk = 0;
+  float* out = c;
+  const int tiles = grid.x * grid.y;
+  if (K >= 4096 && tiles < 256 && !bias && !relu && ldc == N) {
+    S = ceil_div(512, tiles);
+    if (S > ceil_div(K, 512)) S = ceil_div(K, 512);
+    if (S > 1) {
+      kchunk = ceil_div(ceil_div(K, S), LG_BK) * LG_BK;
+      S = ceil_div(K, kchunk);
+      out = head_scratch((size_t)S * M * N * sizeof(float));
+      if (!out) { mmskin_set_error("gemm_f32: split-K scratch allocation failed"); return MMSKIN_ERR_HIP; }
+      grid.z = S;
+    }
+  }
+#define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, out, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu, S > 1 ? kchunk : 0)
   if (akc && bkc) LAUNCH(true, true);
   else if (akc) LAUNCH(true, false);
   else if (bkc) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
+  if (S > 1) {
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, st, out, c, S, n);
+    HIP_CHECK_RET(hipGetLastError());
+  }
   return MMSKIN_OK;
 }
 
@@ -97,13 +148,17 @@ __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __re
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N) {
+// blockIdx.y = row group (rows [y*per, (y+1)*per)) -> out[y*N + n]; one group = plain column sum
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                     int per) {
   __shared__ float red[8][32];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;     // 32 columns x 8 row lanes per block
   const int n = blockIdx.x * 32 + cx;
+  const int m_end = min(M, ((int)blockIdx.y + 1) * per);
+  out += (int64_t)blockIdx.y * N;
   float s = 0.f;
   if (n < N)
-    for (int m = ry; m < M; m += 8) s += x[(int64_t)m * N + n];
+    for (int m = blockIdx.y * per + ry; m < m_end; m += 8) s += x[(int64_t)m * N + n];
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && n < N) {
@@ -179,20 +234,52 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     dx[(int64_t)row * N + i] = rs * (d * g[i] - c1 - xh * c2);
   }
 }
-__global__ void layernorm_bwd_gb_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                        const float* __restrict__ g, const float* __restrict__ b,
-                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                        float* __restrict__ dg, float* __restrict__ db, int M, int N, int relu) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
+static int colsum(const float* x, float* out, int M, int N, hipStream_t st) {
+  const int G = M >= 2048 ? (M / 256 > 128 ? 128 : M / 256) : 1;
+  if (G <= 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, x, out, M, N, M);
+  } else {
+    float* part = head_scratch((size_t)G * N * sizeof(float));
+    if (!part) { mmskin_set_error("colsum: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 32), G), dim3(256), 0, st, x, part, M, N, ceil_div(M, G));
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, part, out, G, (int64_t)N);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// gamma/beta gradients: blockIdx.y = row group -> part[(y*2 + {0,1})*N + n]; 64 columns x 4 row lanes per block
+__global__ __launch_bounds__(256) void layernorm_bwd_gb_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ g, const float* __restrict__ b,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ part, int M, int N, int relu, int per) {
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  const int m_end = min(M, ((int)blockIdx.y + 1) * per);
+  float sg = 0.f, sb = 0.f;
+  if (n < N) {
+    const float gn = g[n], bn = b[n];
+    for (int m = blockIdx.y * per + ry; m < m_end; m += 4) {
+      float xh = (x[(int64_t)m * N + n] - mean[m]) * rstd[m];
+      float d = dy[(int64_t)m * N + n];
+      if (relu && !(xh * gn + bn > 0.f)) d = 0.f;
+      sg += d * xh; sb += d;
+    }
+  }
+  red[0][ry][cx] = sg; red[1][ry][cx] = sb;
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    part[((int64_t)blockIdx.y * 2) * N + n] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+    part[((int64_t)blockIdx.y * 2 + 1) * N + n] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+  }
+}
+// dg[n] = sum_y part[(2y)*N + n], db[n] = sum_y part[(2y+1)*N + n]
+__global__ void layernorm_gb_reduce_kernel(const float* __restrict__ part, float* dg, float* db, int G, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float sg = 0.f, sb = 0.f;
-  const float gn = g[n], bn = b[n];
-  for (int m = 0; m < M; ++m) {
-    float xh = (x[(int64_t)m * N + n] - mean[m]) * rstd[m];
-    float d = dy[(int64_t)m * N + n];
-    if (relu && !(xh * gn + bn > 0.f)) d = 0.f;
-    sg += d * xh; sb += d;
-  }
+  for (int y = 0; y < G; ++y) { sg += part[((int64_t)y * 2) * N + n]; sb += part[((int64_t)y * 2 + 1) * N + n]; }
   if (dg) dg[n] = sg;
   if (db) db[n] = sb;
 }
@@ -519,8 +606,7 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     if ((rc = gemm_f32(g, x, dw, nullptr, N, K, M, 1, N, 1, K, K, 0, st))) return rc;
   }
   if (db) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, g, db, M, N);
-    HIP_CHECK_RET(hipGetLastError());
+    if ((rc = colsum(g, db, M, N, st))) return rc;
   }
   return MMSKIN_OK;
 }
@@ -540,7 +626,13 @@ int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, c
     HIP_CHECK_RET(hipGetLastError());
   }
   if (dg || db) {
-    hipLaunchKernelGGL(layernorm_bwd_gb_kernel, dim3(ceil_div(N, 64)), dim3(64), 0, ST(stream), dy, x, g, b, mean, rstd, dg, db, M, N, relu);
+    int G = ceil_div(M, 64);
+    if (G > 256) G = 256;
+    float* part = head_scratch((size_t)G * 2 * N * sizeof(float));
+    if (!part) { mmskin_set_error("layernorm_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    hipLaunchKernelGGL(layernorm_bwd_gb_kernel, dim3(ceil_div(N, 64), G), dim3(256), 0, ST(stream), dy, x, g, b, mean, rstd,
+                       part, M, N, relu, ceil_div(M, G));
+    hipLaunchKernelGGL(layernorm_gb_reduce_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, ST(stream), part, dg, db, G, N);
     HIP_CHECK_RET(hipGetLastError());
   }
   return MMSKIN_OK;

@@ -36,9 +36,10 @@ template <typename T>
 int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
                   int mask_mode, size_t rows, int C, float* partial, int* nrows_out, hipStream_t st);
 // -> dgamma, dbeta (may be null) and dx = cA*dz + cB*x + cC coefficient vectors
+// n_grad (default C): dgamma / dbeta are written for channels < n_grad only (zero-padded channel tails)
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st);
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad = -1);
 // dx = cA*dz + cB*x + cC ; optionally also writes dz (masked dy) to dz_out
 template <typename T>
 int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,

@@ -380,7 +380,7 @@ template <typename IN>
 __global__ void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                       float* cA, float* cB, float* cC) {
+                                       float* cA, float* cB, float* cC, int n_grad) {
   __shared__ double red[2][4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -397,8 +397,8 @@ __global__ void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows
     s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
     double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
     double dg = is * (s2 - mu * s1);   // sum dz * xhat
-    if (dgamma) dgamma[c] = (float)dg;
-    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma && c < n_grad) dgamma[c] = (float)dg;
+    if (dbeta && c < n_grad) dbeta[c] = (float)s1;
     double A = g * is;
     cA[c] = (float)A;
     cB[c] = (float)(-A * is * dg / count);
@@ -408,16 +408,17 @@ __global__ void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows
 
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st) {
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad) {
+  if (n_grad < 0) n_grad = C;
   if (scratch && nrows > 64) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
   }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;

@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     }
 }
 
-// sum split slabs; write dw[(cout*C + c)*ntaps + tap]  (OIHW when tap = r*kw + s)
+// sum split slabs; write dw[(cout*Cv + c)*ntaps + tap]  (OIHW when tap = r*kw + s) for cout < Coutv, c < Cv:
+// operands padded to the GEMM's 64-multiples (DenseNet) reduce straight into the unpadded parameter gradient
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit,
-                                    int Cout, int C, int ntaps) {
+                                    int Cout, int C, int ntaps, int Coutv, int Cv) {
   const int Ktot = C * ntaps;
   const size_t total = (size_t)Cout * Ktot;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -264,7 +265,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     for (int k = 0; k < nsplit; ++k) s += slab[k * total + i];
     int cout = (int)(i / Ktot), kk = (int)(i - (size_t)cout * Ktot);
     int tap = kk / C, c = kk - tap * C;
-    dw[((size_t)cout * C + c) * ntaps + tap] = s;
+    if (cout < Coutv && c < Cv) dw[((size_t)cout * Cv + c) * ntaps + tap] = s;
   }
 }
 
@@ -322,7 +323,8 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
 
 
 template <typename T>
-static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_layout, hipStream_t st) {
+static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_layout, hipStream_t st,
+                     int cout_valid = 0, int cin_valid = 0) {
   ARG_CHECK(a.Cout % 64 == 0 && a.Ktot % 64 == 0, "wgrad: Cout=%d Ktot=%d must be multiples of 64", a.Cout, a.Ktot);
   ARG_CHECK(a.C % DT<T>::EPC == 0, "wgrad: C=%d", a.C);
   ARG_CHECK(a.OW <= 240 && a.OH <= 240, "wgrad: output %dx%d too large for the 16-bit reciprocal pixel stepping", a.OH, a.OW);
@@ -348,14 +350,15 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
     nsrc = WG_GROUPS;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout,
-                     C_for_layout, ntaps_for_layout);
+                     C_for_layout, ntaps_for_layout, cout_valid > 0 ? cout_valid : a.Cout,
+                     cin_valid > 0 ? cin_valid : C_for_layout);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
 template <typename T>
 int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw_oihw,
-                      hipStream_t st) {
+                      hipStream_t st, int cout_valid, int cin_valid) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "wgrad: too many taps");
   WgradArgs a = {};
   a.dy = dout; a.in = in; a.slab = slab;
@@ -369,7 +372,7 @@ int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* sla
       a.offy[r * s.kw + q] = (int8_t)(r - s.pad);
       a.offx[r * s.kw + q] = (int8_t)(q - s.pad);
     }
-  return run_wgrad<T>(a, dw_oihw, s.Cin, s.kh * s.kw, st);
+  return run_wgrad<T>(a, dw_oihw, s.Cin, s.kh * s.kw, st, cout_valid, cin_valid);
 }
 
 template <typename T>
@@ -387,7 +390,7 @@ int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout,
 }
 
 #define INST(T)                                                                                   \
-  template int launch_conv_wgrad<T>(const ConvShape&, const T*, const T*, float*, float*, hipStream_t); \
+  template int launch_conv_wgrad<T>(const ConvShape&, const T*, const T*, float*, float*, hipStream_t, int, int); \
   template int launch_stem_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t);
 INST(float)
 INST(bf16_t)

@@ -145,7 +145,8 @@ def _chk(got, want, tol=2e-5):
     assert rel_err(got, want) < tol, rel_err(got, want)
 
 
-@pytest.mark.parametrize("M,K,N", [(4, 20, 256), (256, 512, 512), (7, 85, 64), (130, 1024, 6), (33, 2048, 512)])
+@pytest.mark.parametrize("M,K,N", [(4, 20, 256), (256, 512, 512), (7, 85, 64), (130, 1024, 6), (33, 2048, 512),
+                                   (20992, 32, 96), (5003, 128, 32)])   # batch*tokens rows: split-K dW, two-stage bias sum
 @pytest.mark.parametrize("relu", [False, True])
 def test_linear(M, K, N, relu):
     g = torch.Generator().manual_seed(M * N)
@@ -162,7 +163,7 @@ def test_linear(M, K, N, relu):
     _chk(y, y_ref); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad); _chk(bd.grad, br.grad)
 
 
-@pytest.mark.parametrize("M,N", [(4, 64), (256, 512), (9, 2048), (5, 32)])
+@pytest.mark.parametrize("M,N", [(4, 64), (256, 512), (9, 2048), (5, 32), (20992, 32), (4099, 96)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_layernorm(M, N, relu):
     g = torch.Generator().manual_seed(M + N)
