@@ -44,6 +44,10 @@ int64_t mmskin_backbone_param_numel(mmskin_backbone_t h);
 int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h);
 int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h);
 int mmskin_backbone_feature_dim(mmskin_backbone_t h);
+/* spatial size of the plan's output: 1x1 for pooled features; arch "densenet169-features" returns the norm5
+ * feature map [N][1664][H/32][W/32] (fp32 NCHW), the `densenet.features` the reference's MD-Net keeps
+ * (multimodalMDNet.py:72-76) */
+int mmskin_backbone_feature_hw(mmskin_backbone_t h, int* out_h, int* out_w);
 /* Introspection for parity tests: where unit `index` (conv+BN, in parameter order) keeps its raw conv
  * output x, its post-activation output y and its BN coefficient vectors inside the workspace.
  * info12 = {x_off, y_off, coef_off (bytes), rows, Cout, OH, OW, Cin, H, W, pool_off, scratch0_off}. */
@@ -141,6 +145,13 @@ int mmskin_attention_forward(const float* q, const float* k, const float* v, flo
 int mmskin_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* p,
                               float* dq, float* dk, float* dv, int B, int H, int L, int Dh, float drop_p,
                               uint64_t seed, uint64_t offset, void* stream);
+/* MD-Net fusion head (multimodalMDNet.py:21-29 MetaNet gate, :47-55 MetaBlock, :94-100 sum + GAP):
+ * pooled[nc] = mean_hw(sigmoid(z[nc]) * feat[nc][hw] + sigmoid(tanh(feat[nc][hw] * t1[nc]) + t2[nc])), feat NCHW */
+int mmskin_mdnet_fuse_forward(const float* feat, const float* z, const float* t1, const float* t2, float* pooled,
+                              int64_t NC, int HW, void* stream);
+int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const float* z, const float* t1, const float* t2,
+                               float* dfeat /* may be NULL */, float* dz, float* dt1, float* dt2, int64_t NC, int HW,
+                               void* stream);
 /* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
                              void* stream);

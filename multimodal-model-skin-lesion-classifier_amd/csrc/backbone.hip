@@ -491,12 +491,13 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   if (!strcmp(arch, "resnet-18")) a = 18;
   else if (!strcmp(arch, "resnet-50")) a = 50;
   else if (!strcmp(arch, "densenet169")) a = 169;
+  else if (!strcmp(arch, "densenet169-features")) a = 1690;   // norm5 feature map, no ReLU / pool (MDNet)
   else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
   ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
   ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
   int rc = MMSKIN_OK;
-  PlanBase* p = a == 169 ? make_densenet_plan(batch, height, width, dtype, &rc)
-                         : make_resnet_plan(a, batch, height, width, dtype, &rc);
+  PlanBase* p = (a == 169 || a == 1690) ? make_densenet_plan(batch, height, width, dtype, a == 1690, &rc)
+                                        : make_resnet_plan(a, batch, height, width, dtype, &rc);
   if (!p) return rc ? rc : MMSKIN_ERR_ARG;
   mmskin_backbone* h = new mmskin_backbone();
   h->plan = p;
@@ -531,6 +532,11 @@ int64_t mmskin_backbone_param_numel(mmskin_backbone_t h) { return h->plan->param
 int64_t mmskin_backbone_buffer_numel(mmskin_backbone_t h) { return h->plan->buffer_numel; }
 int64_t mmskin_backbone_workspace_bytes(mmskin_backbone_t h) { return (int64_t)h->plan->ws_bytes; }
 int mmskin_backbone_feature_dim(mmskin_backbone_t h) { return h->plan->feat_dim; }
+int mmskin_backbone_feature_hw(mmskin_backbone_t h, int* out_h, int* out_w) {
+  ARG_CHECK(h && out_h && out_w, "backbone_feature_hw: null argument");
+  *out_h = h->plan->out_h; *out_w = h->plan->out_w;
+  return MMSKIN_OK;
+}
 
 int mmskin_backbone_profile_enable(mmskin_backbone_t h, int on) {
   h->plan->prof.on = on != 0;

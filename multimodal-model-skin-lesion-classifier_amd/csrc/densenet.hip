@@ -47,6 +47,7 @@ struct DTrans {
 constexpr int GROWTH = 32, BOTTLE = 128, G_PAD = 64;
 
 struct DensePlan : PlanBase {
+  bool fmap = false;   // "densenet169-features": output = norm5 feature map [N][C][H/32][W/32] fp32 (MDNet), no ReLU / pool
   int Hp, Wp, OH0, OW0, PH, PW;
   // stem
   int64_t w0_off; BNRef n0; int64_t wf0;
@@ -74,9 +75,10 @@ BNRef add_bn(DensePlan& p, const std::string& name, int C) {
 
 int build_dense_plan(DensePlan& p) {
   const int depths[4] = {6, 12, 32, 32};
-  // ---- parameters in torchvision's named_parameters() order
-  p.w0_off = add_tensor(p.params, p.param_numel, "features.conv0.weight", {64, 3, 7, 7});
-  p.n0 = add_bn(p, "features.norm0", 64);
+  // ---- parameters in torchvision's named_parameters() order (MDNet holds densenet.features itself: no prefix)
+  const std::string pre = p.fmap ? "" : "features.";
+  p.w0_off = add_tensor(p.params, p.param_numel, pre + "conv0.weight", {64, 3, 7, 7});
+  p.n0 = add_bn(p, pre + "norm0", 64);
   ConvShape s0 = {p.N, p.H, p.W, 3, 64, 7, 7, 2, 3};
   p.OH0 = s0.OH(); p.OW0 = s0.OW();
   p.Hp = 2 * p.OH0 + 8; p.Wp = 2 * p.OW0 + 8;
@@ -94,7 +96,7 @@ int build_dense_plan(DensePlan& p) {
       DLayer l;
       l.Cin = c + GROWTH * i;
       l.Cp = (l.Cin + 63) / 64 * 64;
-      std::string base = "features.denseblock" + std::to_string(bi + 1) + ".denselayer" + std::to_string(i + 1);
+      std::string base = pre + "denseblock" + std::to_string(bi + 1) + ".denselayer" + std::to_string(i + 1);
       l.n1 = add_bn(p, base + ".norm1", l.Cin);
       l.w1_off = add_tensor(p.params, p.param_numel, base + ".conv1.weight", {BOTTLE, l.Cin, 1, 1});
       l.n2 = add_bn(p, base + ".norm2", BOTTLE);
@@ -105,15 +107,16 @@ int build_dense_plan(DensePlan& p) {
     p.blocks.push_back(b);
     if (bi < 3) {
       DTrans& t = p.trans[bi];
-      std::string base = "features.transition" + std::to_string(bi + 1);
+      std::string base = pre + "transition" + std::to_string(bi + 1);
       t.C = c;
       t.n = add_bn(p, base + ".norm", c);
       t.w_off = add_tensor(p.params, p.param_numel, base + ".conv.weight", {c / 2, c, 1, 1});
       c /= 2; h /= 2; w /= 2;
     }
   }
-  p.n5 = add_bn(p, "features.norm5", c);
+  p.n5 = add_bn(p, pre + "norm5", c);
   p.feat_dim = c;
+  if (p.fmap) { p.out_h = h; p.out_w = w; }
 
   // ---- staged weights + stage table (stem first: its slot needs zeroed padding taps)
   int64_t wf = 0, wd = 0;
@@ -331,7 +334,8 @@ int dense_forward(DensePlan& p, const float* image, const float* params, float* 
   PROF(K_BN_FWD, 0.0, 0.0, bn_coef_from_table(tab, tab + C5, C5, C5, params + p.n5.g_off, params + p.n5.b_off, eps, mom, (double)lb.rows,
                      buffers + p.n5.rm_off, buffers + p.n5.rv_off, training, k5, st));
   PROF(K_BN_FWD, 0.0, 2.0 * lb.rows * C5 * sizeof(T),
-       bn_apply<T>(reinterpret_cast<const T*>(ws + lb.cat_off), nullptr, k5, k5 + C5, nullptr, nullptr, y5, lb.rows, C5, true, st));
+       bn_apply<T>(reinterpret_cast<const T*>(ws + lb.cat_off), nullptr, k5, k5 + C5, nullptr, nullptr, y5, lb.rows, C5, !p.fmap, st));
+  if (p.fmap) return nhwc_to_nchw<T>(y5, p.N, C5, lb.H, lb.W, features, st);
   return avgpool_fwd<T>(y5, p.N, lb.H * lb.W, C5, features, st);
 }
 
@@ -360,12 +364,15 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
     const T* y5 = reinterpret_cast<const T*>(ws + p.y5_off);
     float* cB = cA + C5; float* cC = cA + 2 * C5;
     int nr = 0;
-    if ((rc = avgpool_bwd<T>(dfeat, p.N, lb.H * lb.W, C5, sZ, st))) return rc;
+    const int mode = p.fmap ? MASK_NONE : MASK_FROM_Y;
+    if (p.fmap) rc = nchw_to_nhwc<T>(dfeat, p.N, C5, lb.H, lb.W, sZ, st);
+    else rc = avgpool_bwd<T>(dfeat, p.N, lb.H * lb.W, C5, sZ, st);
+    if (rc) return rc;
     p.prof.begin(K_BN_BWD, st);
-    rc = bn_bwd_reduce<T>(sZ, x, y5, k5, k5 + C5, MASK_FROM_Y, lb.rows, C5, partial, &nr, st);
+    rc = bn_bwd_reduce<T>(sZ, x, y5, k5, k5 + C5, mode, lb.rows, C5, partial, &nr, st);
     if (!rc) rc = bn_bwd_finalize(partial, nr, C5, (double)lb.rows, params + p.n5.g_off, k5 + 2 * C5, k5 + 3 * C5,
                                   grads + p.n5.g_off, grads + p.n5.b_off, cA, cB, cC, red, st);
-    if (!rc) rc = bn_bwd_apply<T>(sZ, x, y5, k5, k5 + C5, MASK_FROM_Y, cA, cB, cC, reinterpret_cast<T*>(ws + lb.dcat_off),
+    if (!rc) rc = bn_bwd_apply<T>(sZ, x, y5, k5, k5 + C5, mode, cA, cB, cC, reinterpret_cast<T*>(ws + lb.dcat_off),
                                   nullptr, lb.rows, C5, st);
     p.prof.end(st);
     if (rc) return rc;
@@ -481,9 +488,9 @@ int DensePlan::backward(const float* dfeat, const float* params, unsigned char* 
 
 }  // namespace
 
-PlanBase* make_densenet_plan(int N, int H, int W, int dtype, int* rc) {
+PlanBase* make_densenet_plan(int N, int H, int W, int dtype, bool feature_map, int* rc) {
   DensePlan* p = new DensePlan();
-  p->N = N; p->H = H; p->W = W; p->dtype = dtype;
+  p->N = N; p->H = H; p->W = W; p->dtype = dtype; p->fmap = feature_map;
   *rc = build_dense_plan(*p);
   if (*rc) { delete p; return nullptr; }
   return p;

@@ -464,6 +464,53 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ MD-Net fusion (multimodalMDNet.py:7-55,88-101)
+// pooled[n][c] = mean_hw( sigmoid(z[n][c]) * f + sigmoid(tanh(f * t1[n][c]) + t2[n][c]) ),  f = feat[n][c][hw]:
+// MetaNet channel gate + spatial MetaBlock + element-wise sum + global average pool in one pass over the
+// feature map (NCHW fp32); one 64-lane wave per (n, c) plane.
+__global__ __launch_bounds__(256) void mdnet_fuse_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ z,
+                                                             const float* __restrict__ t1, const float* __restrict__ t2,
+                                                             float* __restrict__ pooled, int64_t NC, int HW) {
+  const int64_t nc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nc >= NC) return;
+  const int lane = threadIdx.x & 63;
+  const float g = 1.f / (1.f + expf(-z[nc])), a = t1[nc], b = t2[nc];
+  float s = 0.f;
+  for (int i = lane; i < HW; i += 64) {
+    float f = feat[nc * HW + i];
+    s += g * f + 1.f / (1.f + expf(-(tanhf(f * a) + b)));
+  }
+  s = wave_sum(s);
+  if (lane == 0) pooled[nc] = s / (float)HW;
+}
+__global__ __launch_bounds__(256) void mdnet_fuse_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ feat,
+                                                             const float* __restrict__ z, const float* __restrict__ t1,
+                                                             const float* __restrict__ t2, float* __restrict__ dfeat,
+                                                             float* __restrict__ dz, float* __restrict__ dt1,
+                                                             float* __restrict__ dt2, int64_t NC, int HW) {
+  const int64_t nc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (nc >= NC) return;
+  const int lane = threadIdx.x & 63;
+  const float g = 1.f / (1.f + expf(-z[nc])), a = t1[nc], b = t2[nc];
+  const float dp = dpooled[nc] / (float)HW;
+  float sf = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < HW; i += 64) {
+    float f = feat[nc * HW + i];
+    float u = tanhf(f * a);
+    float o = 1.f / (1.f + expf(-(u + b)));
+    float ds = dp * o * (1.f - o);        // d/d(u + b)
+    float du = ds * (1.f - u * u);        // d/d(f * a)
+    if (dfeat) dfeat[nc * HW + i] = dp * g + du * a;
+    sf += f; s1 += du * f; s2 += ds;
+  }
+  sf = wave_sum(sf); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) {
+    dz[nc] = dp * sf * g * (1.f - g);
+    dt1[nc] = s1;
+    dt2[nc] = s2;
+  }
+}
+
 // ------------------------------------------------------------------ embedding
 __global__ void embedding_fwd_kernel(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E) {
   EW_LOOP((int64_t)B * ncols * E) {
@@ -696,6 +743,22 @@ int mmskin_attention_backward(const float* dO, const float* q, const float* k, c
   ARG_CHECK(dO && q && k && v && p && dq && dk && dv, "attention_backward: null argument");
   ARG_CHECK((size_t)L * L * 4 <= 64 * 1024, "attention_backward: L=%d too long", L);
   hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), (size_t)L * L * 4, ST(stream), dO, q, k, v, p, dq, dk, dv, L, Dh, drop_p, seed, offset);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+int mmskin_mdnet_fuse_forward(const float* feat, const float* z, const float* t1, const float* t2, float* pooled,
+                              int64_t NC, int HW, void* stream) {
+  ARG_CHECK(feat && z && t1 && t2 && pooled && NC > 0 && HW > 0, "mdnet_fuse_forward: bad argument");
+  hipLaunchKernelGGL(mdnet_fuse_fwd_kernel, dim3((unsigned)((NC + 3) / 4)), dim3(256), 0, ST(stream), feat, z, t1, t2, pooled, NC, HW);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const float* z, const float* t1, const float* t2,
+                               float* dfeat, float* dz, float* dt1, float* dt2, int64_t NC, int HW, void* stream) {
+  ARG_CHECK(dpooled && feat && z && t1 && t2 && dz && dt1 && dt2 && NC > 0 && HW > 0, "mdnet_fuse_backward: bad argument");
+  hipLaunchKernelGGL(mdnet_fuse_bwd_kernel, dim3((unsigned)((NC + 3) / 4)), dim3(256), 0, ST(stream), dpooled, feat, z, t1, t2,
+                     dfeat, dz, dt1, dt2, NC, HW);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -78,6 +78,7 @@ struct PlanBase {
   SideStream side;
   int N = 0, H = 0, W = 0, dtype = 0;
   int feat_dim = 0;
+  int out_h = 1, out_w = 1;   // spatial size of the output (1x1 = pooled features; >1 for feature-map plans)
   std::vector<TensorInfo> params, buffers;
   int64_t param_numel = 0, buffer_numel = 0;
   StageDesc* table_dev = nullptr;
@@ -148,4 +149,4 @@ static inline double conv_bytes(const ConvShape& s, size_t es, int extra_in_shap
 
 // plan factories (create() needs no GPU); return nullptr and set *rc on failure
 PlanBase* make_resnet_plan(int arch, int N, int H, int W, int dtype, int* rc);
-PlanBase* make_densenet_plan(int N, int H, int W, int dtype, int* rc);
+PlanBase* make_densenet_plan(int N, int H, int W, int dtype, bool feature_map, int* rc);

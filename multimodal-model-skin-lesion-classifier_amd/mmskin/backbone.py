@@ -57,6 +57,9 @@ class _Plan:
         self.handle = h
         lib = _lib.load()
         self.feat_dim = lib.mmskin_backbone_feature_dim(h)
+        oh, ow = ctypes.c_int(), ctypes.c_int()
+        call("mmskin_backbone_feature_hw", h, ctypes.byref(oh), ctypes.byref(ow))
+        self.out_hw = (oh.value, ow.value)
         self.param_numel = lib.mmskin_backbone_param_numel(h)
         self.ws_bytes = lib.mmskin_backbone_workspace_bytes(h)
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device) if device is not None else None
@@ -87,7 +90,8 @@ class _BackboneFn(torch.autograd.Function):
         image = image.float().contiguous()
         N, _, H, W = image.shape
         plan = module._plan_for(N, H, W, image.device)
-        feats = torch.empty((N, plan.feat_dim), device=image.device, dtype=torch.float32)
+        shape = (N, plan.feat_dim) if plan.out_hw == (1, 1) else (N, plan.feat_dim) + plan.out_hw
+        feats = torch.empty(shape, device=image.device, dtype=torch.float32)
         call("mmskin_backbone_forward", plan.handle, ptr(image), ptr(module._flat_p), ptr(module._flat_b),
              ptr(plan.workspace), ptr(feats), int(training), stream())
         ctx.plan = plan
@@ -277,6 +281,26 @@ class _Features(nn.Module):
     pass
 
 
+def _build_densenet169_features(f):
+    """Adds torchvision's densenet169 `.features` children to module f; returns the output channel count."""
+    growth, bn_size, c = 32, 4, 64
+    f.conv0 = nn.Conv2d(3, c, 7, stride=2, padding=3, bias=False)
+    f.norm0 = nn.BatchNorm2d(c)
+    f.relu0 = nn.ReLU(inplace=True)
+    f.pool0 = nn.MaxPool2d(3, stride=2, padding=1)
+    for bi, n in enumerate((6, 12, 32, 32), start=1):
+        setattr(f, f"denseblock{bi}", _DenseBlock(n, c, growth, bn_size))
+        c += growth * n
+        if bi < 4:
+            setattr(f, f"transition{bi}", _Transition(c, c // 2))
+            c //= 2
+    f.norm5 = nn.BatchNorm2d(c)
+    for m in f.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight)
+    return c
+
+
 class HipDenseNet(_FlatBackbone):
     """torchvision densenet169 (growth 32, blocks 6/12/32/32, bn_size 4) with `classifier = Identity`
     (loadImageModelClassifier.py:84-92) -> 1664 features."""
@@ -286,25 +310,22 @@ class HipDenseNet(_FlatBackbone):
         if name != "densenet169":
             raise ValueError(f"Backbone '{name}' não implementado.")
         self.arch = name
-        growth, bn_size, c = 32, 4, 64
         f = _Features()
-        f.conv0 = nn.Conv2d(3, c, 7, stride=2, padding=3, bias=False)
-        f.norm0 = nn.BatchNorm2d(c)
-        f.relu0 = nn.ReLU(inplace=True)
-        f.pool0 = nn.MaxPool2d(3, stride=2, padding=1)
-        for bi, n in enumerate((6, 12, 32, 32), start=1):
-            setattr(f, f"denseblock{bi}", _DenseBlock(n, c, growth, bn_size))
-            c += growth * n
-            if bi < 4:
-                setattr(f, f"transition{bi}", _Transition(c, c // 2))
-                c //= 2
-        f.norm5 = nn.BatchNorm2d(c)
+        c = _build_densenet169_features(f)
         self.features = f
         self.classifier = nn.Identity()
         self.num_features = c
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight)
+        self._init_flat(compute_dtype)
+
+
+class HipDenseNetFeatures(_FlatBackbone):
+    """torchvision `densenet169(...).features` as the reference's MD-Net holds it (multimodalMDNet.py:72-76):
+    conv0 ... norm5, no final ReLU / pooling; forward returns the feature map [N, 1664, H/32, W/32] (fp32)."""
+
+    def __init__(self, compute_dtype=None):
+        super().__init__()
+        self.arch = "densenet169-features"
+        self.num_features = _build_densenet169_features(self)
         self._init_flat(compute_dtype)
 
 

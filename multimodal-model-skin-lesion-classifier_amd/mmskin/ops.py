@@ -265,6 +265,34 @@ def attention(q, k, v, dropout_p=0.0, training=False):
 
 
 
+class MDNetFuseFn(torch.autograd.Function):
+    """mean_hw(sigmoid(z) * f + sigmoid(tanh(f * t1) + t2)) for f [N, C, H, W]; z, t1, t2 [N, C] -> [N, C]."""
+
+    @staticmethod
+    def forward(ctx, feat, z, t1, t2):
+        _need_gpu(feat, "mdnet_fuse")
+        feat, z, t1, t2 = _f32c(feat), _f32c(z), _f32c(t1), _f32c(t2)
+        N, C, H, W = feat.shape
+        pooled = torch.empty((N, C), device=feat.device, dtype=torch.float32)
+        call("mmskin_mdnet_fuse_forward", ptr(feat), ptr(z), ptr(t1), ptr(t2), ptr(pooled), N * C, H * W, stream())
+        ctx.save_for_backward(feat, z, t1, t2)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        feat, z, t1, t2 = ctx.saved_tensors
+        N, C, H, W = feat.shape
+        dp = _f32c(dp)
+        dfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None
+        dz, dt1, dt2 = torch.empty_like(z), torch.empty_like(t1), torch.empty_like(t2)
+        call("mmskin_mdnet_fuse_backward", ptr(dp), ptr(feat), ptr(z), ptr(t1), ptr(t2),
+             ptr(dfeat) if dfeat is not None else None, ptr(dz), ptr(dt1), ptr(dt2), N * C, H * W, stream())
+        return dfeat, dz, dt1, dt2
+
+
+mdnet_fuse = MDNetFuseFn.apply
+
+
 class EmbeddingFn(torch.autograd.Function):
     """table [ncols, card, E], ids [B, ncols] -> [B, ncols, E]."""
 

@@ -131,13 +131,38 @@ def gen_seed_equivalence(ref):
             "sums": {k: float(v.double().sum()) for k, v in m.state_dict().items()}}
 
 
+def gen_alt_models(ref):
+    """MD-Net (multimodalMDNet.py) and MetaNet+ResNet (metanet.py) through the reference's own classes.  Their
+    constructors fetch torchvision / timm backbones by name (absent here): for this fixture those two
+    constructor calls return this package's restated backbones, so the fixture pins the reference's head /
+    fusion code and the state_dict key layout, not the third-party backbone arithmetic."""
+    import importlib
+    import sys
+    from .altmodels import OracleResNetFeatureMaps
+    from .backbones import OracleDenseNet169
+    sys.modules["torchvision.models"].densenet169 = lambda pretrained=True: OracleDenseNet169()
+    sys.modules["timm"].create_model = lambda name, pretrained=True, num_classes=0, global_pool="": \
+        OracleResNetFeatureMaps({"resnet50": "resnet-50", "resnet18": "resnet-18"}[name])
+    out = {}
+    img, meta, lab = det_inputs(3, 64, 20, 6)
+    mdnet = importlib.import_module("multimodalMDNet").MDNet(meta_dim=20, num_classes=6, unfreeze_weights=True)
+    out["mdnet"] = step_record(det_init_(mdnet), img, meta, lab)
+    out["mdnet"]["keys"] = list(mdnet.state_dict().keys())
+    mn = importlib.import_module("metanet").MetaNetModel(meta_dim=20, num_classes=6, image_encoder="resnet18",
+                                                         unfreeze_weights=True)
+    out["metanet"] = step_record(det_init_(mn), img, meta, lab)
+    out["metanet"]["keys"] = list(mn.state_dict().keys())
+    return out
+
+
 def main():
     assert ref_import.available(), "reference not mounted"
     ref = ref_import.load()
     torch.set_num_threads(1)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     for name, fn in (("mechanisms", gen_mechanisms), ("full_width", gen_full_width),
-                     ("blocks", gen_blocks), ("seed_equivalence", gen_seed_equivalence)):
+                     ("blocks", gen_blocks), ("seed_equivalence", gen_seed_equivalence),
+                     ("alt_models", gen_alt_models)):
         with open(os.path.join(GOLDEN_DIR, name + ".json"), "w") as f:
             json.dump(fn(ref), f, indent=0)
         print("wrote", name)

@@ -101,3 +101,27 @@ def test_freeze_policy():
         net, dim = loadModels.loadModelImageEncoder("resnet-50", 512, mode)
         assert dim == 2048
         assert sum(p.requires_grad for p in net.parameters()) == expect
+
+
+def test_alternate_model_drop_ins_key_layout():
+    """models/multimodalMDNet.py and models/metanet.py: same state_dict keys / shapes as the reference classes
+    (fixture keys) and as the oracle restatements; constructible without a GPU."""
+    from helpers import golden
+    from models.metanet import MetaNetModel
+    from models.multimodalMDNet import MDNet
+    from oracle.altmodels import OracleMDNet, OracleMetaNetModel
+    gold = golden("alt_models")
+    hip = MDNet(meta_dim=20, num_classes=6, unfreeze_weights=True)
+    ora = OracleMDNet(meta_dim=20, num_classes=6, unfreeze_weights=True)
+    assert list(hip.state_dict().keys()) == gold["mdnet"]["keys"]
+    assert {k: tuple(v.shape) for k, v in hip.state_dict().items()} == {k: tuple(v.shape) for k, v in ora.state_dict().items()}
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    assert all(p.requires_grad for p in hip.parameters())
+    assert not any(p.requires_grad for p in MDNet(meta_dim=20).feature_extractor.parameters())      # reference :73-75
+    hip = MetaNetModel(meta_dim=20, num_classes=6, image_encoder="resnet18", unfreeze_weights=True)
+    ora = OracleMetaNetModel(meta_dim=20, num_classes=6, image_encoder="resnet18", unfreeze_weights=True)
+    assert list(hip.state_dict().keys()) == gold["metanet"]["keys"]
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        MetaNetModel(meta_dim=20, image_encoder="vit_large_patch16_224")
