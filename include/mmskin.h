@@ -64,6 +64,11 @@ int mmskin_backbone_profile_read(mmskin_backbone_t h, double* ms7, double* flops
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
                             void* workspace, float* features, int training, void* stream);
 /* param_grads: flat fp32, same layout as params; every element is written. */
+/* Same forward from the uint8 NHWC batch the DataLoader decodes ([N][H][W][3]): Normalize + ToTensor of the
+ * reference's transform (skinLesionDatasets.py:29,111-119: (u8/255 - mean)/std) run inside the stem packing
+ * kernel, so the host->device copy is 1 byte per value instead of 4.  mean_std6: 6 HOST floats, mean rgb | std rgb. */
+int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, const float* mean_std6, const float* params,
+                               float* buffers, void* workspace, float* features, int training, void* stream);
 int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,
                              float* param_grads, void* stream);
 

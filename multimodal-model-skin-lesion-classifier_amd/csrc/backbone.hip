@@ -42,8 +42,8 @@ struct Plan : PlanBase {
       off_coefbwd, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
 
-  int forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
-              bool training, hipStream_t st) override;
+  int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+              float* features, bool training, hipStream_t st) override;
   int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) override;
   int num_units() const override { return (int)units.size(); }
   int unit_info(int index, std::string* name, int64_t* info12) const override;
@@ -180,7 +180,7 @@ int build_plan(Plan& p) {
 }
 
 template <typename T>
-int forward_impl(Plan& p, const float* image, const float* params, float* buffers, unsigned char* ws,
+int forward_impl(Plan& p, const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
                  float* features, bool training, hipStream_t st) {
   const float eps = 1e-5f, mom = 0.1f;
   T* wf = reinterpret_cast<T*>(ws + p.off_wf);
@@ -216,7 +216,8 @@ int forward_impl(Plan& p, const float* image, const float* params, float* buffer
   // ---- stem
   Unit& u0 = p.units[0];
   T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
-  PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
+  if (norm6) PROF(K_STEM_MISC, 0.0, 0.0, stem_pack_u8<T>((const uint8_t*)image, p.N, p.H, p.W, p.Hp, p.Wp, norm6, img4, st));
+  else PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>((const float*)image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
   PROF(K_CONV_FWD, conv_flops(u0.s), conv_bytes(u0.s, sizeof(T)),
        launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
@@ -448,10 +449,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   return stem_wgrad_unpack(dwv, grads + u0.w_off, st);
 }
 
-int Plan::forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
-                  bool training, hipStream_t st) {
-  if (dtype == 1) return forward_impl<bf16_t>(*this, image, params, buffers, ws, features, training, st);
-  return forward_impl<float>(*this, image, params, buffers, ws, features, training, st);
+int Plan::forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+                  float* features, bool training, hipStream_t st) {
+  if (dtype == 1) return forward_impl<bf16_t>(*this, image, norm6, params, buffers, ws, features, training, st);
+  return forward_impl<float>(*this, image, norm6, params, buffers, ws, features, training, st);
 }
 int Plan::backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) {
   if (dtype == 1) return backward_impl<bf16_t>(*this, dfeat, params, ws, grads, st);
@@ -572,7 +573,14 @@ int mmskin_backbone_unit_info(mmskin_backbone_t h, int index, char* name, int na
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
                             void* workspace, float* features, int training, void* stream) {
   ARG_CHECK(h && image_nchw && params && buffers && workspace && features, "backbone_forward: null argument");
-  return h->plan->forward(image_nchw, params, buffers, (unsigned char*)workspace, features, training != 0,
+  return h->plan->forward(image_nchw, nullptr, params, buffers, (unsigned char*)workspace, features, training != 0,
+                          (hipStream_t)stream);
+}
+
+int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, const float* mean_std6, const float* params,
+                               float* buffers, void* workspace, float* features, int training, void* stream) {
+  ARG_CHECK(h && image_nhwc && mean_std6 && params && buffers && workspace && features, "backbone_forward_u8: null argument");
+  return h->plan->forward(image_nhwc, mean_std6, params, buffers, (unsigned char*)workspace, features, training != 0,
                           (hipStream_t)stream);
 }
 

@@ -59,8 +59,8 @@ struct DensePlan : PlanBase {
   size_t off_sB, off_sU, off_sA, off_sX, off_sZ, off_sC;
   size_t stat_bytes = 0;
 
-  int forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
-              bool training, hipStream_t st) override;
+  int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+              float* features, bool training, hipStream_t st) override;
   int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) override;
 };
 
@@ -224,8 +224,8 @@ int build_dense_plan(DensePlan& p) {
 }
 
 template <typename T>
-int dense_forward(DensePlan& p, const float* image, const float* params, float* buffers, unsigned char* ws,
-                  float* features, bool training, hipStream_t st) {
+int dense_forward(DensePlan& p, const void* image, const float* norm6, const float* params, float* buffers,
+                  unsigned char* ws, float* features, bool training, hipStream_t st) {
   const float eps = 1e-5f, mom = 0.1f;
   T* wf = reinterpret_cast<T*>(ws + p.off_wf);
   T* wd = reinterpret_cast<T*>(ws + p.off_wd);
@@ -250,7 +250,8 @@ int dense_forward(DensePlan& p, const float* image, const float* params, float* 
 
   // ---- stem: conv0 (7x7 s2) -> norm0 -> relu -> maxpool 3x3 s2
   T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
-  PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>(image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
+  if (norm6) PROF(K_STEM_MISC, 0.0, 0.0, stem_pack_u8<T>((const uint8_t*)image, p.N, p.H, p.W, p.Hp, p.Wp, norm6, img4, st));
+  else PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>((const float*)image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + p.x0_off);
   ConvShape s0 = {p.N, p.H, p.W, 3, 64, 7, 7, 2, 3};
   PROF(K_CONV_FWD, conv_flops(s0), conv_bytes(s0, sizeof(T)),
@@ -476,10 +477,10 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
   }
 }
 
-int DensePlan::forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
-                       bool training, hipStream_t st) {
-  if (dtype == 1) return dense_forward<bf16_t>(*this, image, params, buffers, ws, features, training, st);
-  return dense_forward<float>(*this, image, params, buffers, ws, features, training, st);
+int DensePlan::forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+                       float* features, bool training, hipStream_t st) {
+  if (dtype == 1) return dense_forward<bf16_t>(*this, image, norm6, params, buffers, ws, features, training, st);
+  return dense_forward<float>(*this, image, norm6, params, buffers, ws, features, training, st);
 }
 int DensePlan::backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) {
   if (dtype == 1) return dense_backward<bf16_t>(*this, dfeat, params, ws, grads, st);

@@ -50,6 +50,11 @@ int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, co
 // NCHW fp32 image -> zero-padded NHWC4 T image [N][Hp][Wp][4] (3 px top/left border)
 template <typename T>
 int stem_pack(const float* img, int N, int H, int W, int Hp, int Wp, T* img4, hipStream_t st);
+// same from a uint8 NHWC image (what the DataLoader decodes), normalised on the fly:
+// v = (u8 / 255 - mean[c]) / std[c]  (A.Normalize + ToTensorV2, skinLesionDatasets.py:29,111-119); norm6 = mean rgb | std rgb (host)
+template <typename T>
+int stem_pack_u8(const uint8_t* img_nhwc, int N, int H, int W, int Hp, int Wp, const float* norm6, T* img4,
+                 hipStream_t st);
 // y = maxpool3x3s2p1(relu(x*scale+shift)); idx = argmax tap (first max, row-major), 0..8
 template <typename T>
 int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N, int H, int W, int C,

@@ -494,6 +494,47 @@ int stem_pack(const float* img, int N, int H, int W, int Hp, int Wp, T* img4, hi
   return MMSKIN_OK;
 }
 
+struct Norm6 { float a[3], b[3]; };   // v = u8 * a[c] + b[c]
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void stem_pack_u8_kernel(const uint8_t* __restrict__ img, int N, int H, int W,
+                                                               int Hp, int Wp, Norm6 nm, T* __restrict__ out) {
+  const size_t total = (size_t)N * Hp * Wp;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int wp = (int)(i % Wp);
+    size_t t = i / Wp;
+    int hp = (int)(t % Hp), n = (int)(t / Hp);
+    int h = hp - 3, w = wp - 3;
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      const uint8_t* px = img + (((size_t)n * H + h) * W + w) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (float)px[c] * nm.a[c] + nm.b[c];
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(out + i * 4) = make_float4(v[0], v[1], v[2], 0.f);
+    } else {
+      uint32_t lo = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+      uint32_t hi = f32_to_bf16_bits(v[2]);
+      *reinterpret_cast<uint2*>(out + i * 4) = make_uint2(lo, hi);
+    }
+  }
+}
+template <typename T>
+int stem_pack_u8(const uint8_t* img_nhwc, int N, int H, int W, int Hp, int Wp, const float* norm6, T* img4,
+                 hipStream_t st) {
+  ARG_CHECK(Hp >= H + 6 && Wp >= W + 6 && Wp % 2 == 0, "stem_pack_u8: bad padded size");
+  Norm6 nm;
+  for (int c = 0; c < 3; ++c) {
+    ARG_CHECK(norm6[3 + c] > 0.f, "stem_pack_u8: std[%d] = %f", c, norm6[3 + c]);
+    nm.a[c] = 1.f / (255.f * norm6[3 + c]);
+    nm.b[c] = -norm6[c] / norm6[3 + c];
+  }
+  hipLaunchKernelGGL(stem_pack_u8_kernel<T>, dim3(ew_grid((size_t)N * Hp * Wp)), dim3(EW_BLOCK), 0, st, img_nhwc, N, H, W, Hp,
+                     Wp, nm, img4);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void stem_bn_relu_pool_kernel(const T* __restrict__ x,
                                                                     const float* __restrict__ scale,
@@ -777,6 +818,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
   template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, int*, hipStream_t); \
   template int bn_bwd_apply<T>(const T*, const T*, const T*, const float*, const float*, int, const float*, const float*, const float*, T*, T*, size_t, int, hipStream_t); \
   template int stem_pack<T>(const float*, int, int, int, int, int, T*, hipStream_t);                            \
+  template int stem_pack_u8<T>(const uint8_t*, int, int, int, int, int, const float*, T*, hipStream_t);        \
   template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \
   template int maxpool_bwd<T>(const T*, const uint8_t*, int, int, int, int, T*, hipStream_t);                   \
   template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \

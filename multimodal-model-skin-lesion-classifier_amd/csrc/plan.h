@@ -91,8 +91,9 @@ struct PlanBase {
     if (table_dev) (void)hipFree(table_dev);
     side.destroy();
   }
-  virtual int forward(const float* image, const float* params, float* buffers, unsigned char* ws, float* features,
-                      bool training, hipStream_t st) = 0;
+  // image: fp32 NCHW, or (norm6 != nullptr) uint8 NHWC normalised on the fly with the 6 host floats mean rgb | std rgb
+  virtual int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+                      float* features, bool training, hipStream_t st) = 0;
   virtual int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) = 0;
   // per-unit introspection (tests / diagnostics); plans without it report zero units
   virtual int num_units() const { return 0; }

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mmskin_backbone_num_units": (_i, [_P]),
     "mmskin_backbone_unit_info": (_i, [_P, _i, ctypes.c_char_p, _i, ctypes.POINTER(_i64)]),
     "mmskin_backbone_forward": (_i, [_P, _P, _P, _P, _P, _P, _i, _P]),
+    "mmskin_backbone_forward_u8": (_i, [_P, _P, _P, _P, _P, _P, _P, _i, _P]),
     "mmskin_backbone_backward": (_i, [_P, _P, _P, _P, _P, _P]),
     "mmskin_conv2d_workspace_bytes": (_i64, [_i] * 9),
     "mmskin_conv2d_forward": (_i, [_P, _P, _P] + [_i] * 10 + [_P, _P]),

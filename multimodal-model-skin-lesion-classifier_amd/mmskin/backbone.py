@@ -87,13 +87,25 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, module, training, *params):
         ops._need_gpu(image, "image_encoder")
-        image = image.float().contiguous()
-        N, _, H, W = image.shape
+        u8 = image.dtype == torch.uint8
+        if u8:   # raw decoded batch [N, H, W, 3]: normalisation + layout change happen inside the stem packing kernel
+            if image.dim() != 4 or image.shape[-1] != 3:
+                raise _lib.MMSkinError(f"uint8 images must be NHWC [N, H, W, 3], got {tuple(image.shape)}")
+            image = image.contiguous()
+            N, H, W, _ = image.shape
+        else:
+            image = image.float().contiguous()
+            N, _, H, W = image.shape
         plan = module._plan_for(N, H, W, image.device)
         shape = (N, plan.feat_dim) if plan.out_hw == (1, 1) else (N, plan.feat_dim) + plan.out_hw
         feats = torch.empty(shape, device=image.device, dtype=torch.float32)
-        call("mmskin_backbone_forward", plan.handle, ptr(image), ptr(module._flat_p), ptr(module._flat_b),
-             ptr(plan.workspace), ptr(feats), int(training), stream())
+        if u8:
+            norm6 = (ctypes.c_float * 6)(*module.input_mean, *module.input_std)
+            call("mmskin_backbone_forward_u8", plan.handle, ptr(image), norm6, ptr(module._flat_p), ptr(module._flat_b),
+                 ptr(plan.workspace), ptr(feats), int(training), stream())
+        else:
+            call("mmskin_backbone_forward", plan.handle, ptr(image), ptr(module._flat_p), ptr(module._flat_b),
+                 ptr(plan.workspace), ptr(feats), int(training), stream())
         ctx.plan = plan
         ctx.module = module
         ctx.training_fwd = training
@@ -126,6 +138,10 @@ class _BackboneFn(torch.autograd.Function):
 class _FlatBackbone(nn.Module):
     """Parameter arena + plan cache shared by the plan-executed backbones.  Sub-classes build the
     torchvision-named module tree, set `self.arch`, then call `_init_flat()`."""
+
+    # Normalisation applied to uint8 NHWC inputs (skinLesionDatasets.py:29: ImageNet mean / std on the 0..1 scale)
+    input_mean = (0.485, 0.456, 0.406)
+    input_std = (0.229, 0.224, 0.225)
 
     def _init_flat(self, compute_dtype):
         self.compute_dtype = (compute_dtype or default_compute_dtype()).lower()

@@ -257,3 +257,26 @@ def test_checkpoint_round_trip_and_module_prefix():
     with torch.no_grad():
         assert torch.equal(a(img.to(DEV), meta.to(DEV)), b(img.to(DEV), meta.to(DEV)))
     assert b.image_encoder._packed()
+
+
+@pytest.mark.parametrize("arch", ["resnet-18", "densenet169"])
+def test_uint8_nhwc_input_path(arch):
+    """the decoded uint8 NHWC batch goes straight into the stem packing kernel, which applies the
+    reference transform's Normalize + ToTensor (skinLesionDatasets.py:29,111-119).  Must equal feeding the
+    normalised fp32 NCHW tensor, through the model's forward (MultimodalModel moves / forwards the tensor as is)."""
+    kw = dict(SMALL, cnn_model_name=arch, attention_mecanism="concatenation")
+    cpu, hip = build_pair("fp32", **kw)
+    cpu.eval(); hip.eval()
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (3, 64, 64, 3), generator=g, dtype=torch.uint8)
+    meta = det_inputs(3, 32, 20, 6)[1]
+    mean = torch.tensor([0.485, 0.456, 0.406]); std = torch.tensor([0.229, 0.224, 0.225])
+    x = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        a = hip(u8.to(DEV), meta.to(DEV)).cpu()
+        b = hip(x.to(DEV), meta.to(DEV)).cpu()
+        c = cpu(x, meta)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a - b).abs().max()
+    assert torch.allclose(a, c, rtol=1e-3, atol=1e-4), (a - c).abs().max()
+    with pytest.raises(Exception):
+        hip.image_encoder(torch.zeros(2, 3, 64, 64, dtype=torch.uint8, device=DEV))     # uint8 must be NHWC
