@@ -35,6 +35,7 @@ struct ConvGemmArgs {
   const void* ep_mask_y;   // mask = (ep_mask_y > 0)      (ReLU after a residual add: mask from the block output)
   const uint8_t* ep_mask_bits;  // or: the same mask as one byte per 16-byte chunk (written by bn_apply)
   const void* ep_x;        // raw BN input x of the consumer unit (same shape as out)
+  int ep_x_pitch;          // 0: ep_x rows are Cout elements apart (compact); else the row pitch of ep_x in elements
   const float* ep_scale;   // with ep_shift: mask = (ep_x*scale + shift > 0)   (plain BN+ReLU)
   const float* ep_shift;
   const void* ep_x2;       // second raw tensor (downsample BN of the same block) -> stat_b_*
@@ -82,6 +83,7 @@ struct DgradFuse {
   const void* mask_y = nullptr;
   const uint8_t* mask_bits = nullptr;   // alternative to mask_y: 1 bit per element (1/16 of the bytes)
   const void* x = nullptr;
+  int x_pitch = 0;              // row pitch of x in elements when x is a channel prefix of a wider tensor (0 = compact)
   const float* scale = nullptr;
   const float* shift = nullptr;
   const void* x2 = nullptr;

@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
         q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
         q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
-        q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + goffs[k] : zp);
+        // ep_x may be a channel prefix of a wider (concatenated) tensor: its rows are ep_x_pitch elements apart
+        const size_t xoff = p.ep_x_pitch ? ((size_t)orow * p.ep_x_pitch + n0 + cj * EPC) * sizeof(T) : goffs[k];
+        q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + xoff : zp);
         q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
       }
     }
@@ -452,7 +454,7 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   if (fuse) {
     ARG_CHECK(!(addend == din && addend != nullptr && s.stride != 1 && s.kh == 1),
               "conv_dgrad: epilogue fusion needs a launch that covers every output pixel");
-    a.ep_mask_y = fuse->mask_y; a.ep_mask_bits = fuse->mask_bits; a.ep_x = fuse->x; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
+    a.ep_mask_y = fuse->mask_y; a.ep_mask_bits = fuse->mask_bits; a.ep_x = fuse->x; a.ep_x_pitch = fuse->x_pitch; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
     a.ep_x2 = fuse->x2;
     a.stat_stride = 2 * s.Cin;
     a.stat_sum = fuse->partial; a.stat_sq = fuse->partial + s.Cin;

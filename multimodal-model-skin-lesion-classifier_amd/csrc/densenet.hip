@@ -56,8 +56,26 @@ struct DensePlan : PlanBase {
   DTrans trans[3];
   BNRef n5; size_t coef5_off, y5_off;
   size_t off_wf, off_wd, off_stat, off_partial, off_coefbwd, off_dwv, off_red, off_slab;
-  size_t off_sB, off_sU, off_sA, off_sX, off_sZ, off_sC;
+  size_t off_sB, off_sB2, off_sU, off_sA, off_sA2, off_sX, off_sZ, off_sC;
   size_t stat_bytes = 0;
+  // weight-gradient GEMMs on the side stream: slots 0/1 = conv2 operand (sB) of even/odd layers, 2/3 = conv1
+  // operand (sA) of even/odd layers, 4 = transition operand (sC)
+  hipEvent_t ev_ready[5] = {}, ev_done[5] = {};
+  bool ev_valid[5] = {};
+  ~DensePlan() override {
+    for (int i = 0; i < 5; ++i) {
+      if (ev_ready[i]) (void)hipEventDestroy(ev_ready[i]);
+      if (ev_done[i]) (void)hipEventDestroy(ev_done[i]);
+    }
+  }
+  int init_events() {
+    if (ev_ready[0]) return MMSKIN_OK;
+    for (int i = 0; i < 5; ++i) {
+      HIP_CHECK_RET(hipEventCreateWithFlags(&ev_ready[i], hipEventDisableTiming));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&ev_done[i], hipEventDisableTiming));
+    }
+    return MMSKIN_OK;
+  }
 
   int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
               float* features, bool training, hipStream_t st) override;
@@ -214,8 +232,10 @@ int build_dense_plan(DensePlan& p) {
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.off_slab = carve(cur, slab);
   p.off_sB = carve(cur, p.blocks[0].rows * G_PAD * es);
+  p.off_sB2 = carve(cur, p.blocks[0].rows * G_PAD * es);
   p.off_sU = carve(cur, small_elems * es);
   p.off_sA = carve(cur, small_elems * es);
+  p.off_sA2 = carve(cur, small_elems * es);
   p.off_sX = carve(cur, big_elems * es);
   p.off_sZ = carve(cur, big_elems * es);
   p.off_sC = carve(cur, big_elems * es);
@@ -348,13 +368,48 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
   float* partial = reinterpret_cast<float*>(ws + p.off_partial);
   float* cA = reinterpret_cast<float*>(ws + p.off_coefbwd);
   double* red = reinterpret_cast<double*>(ws + p.off_red);
-  T* sB = reinterpret_cast<T*>(ws + p.off_sB);
+  T* sBq[2] = {reinterpret_cast<T*>(ws + p.off_sB), reinterpret_cast<T*>(ws + p.off_sB2)};
+  T* sAq[2] = {reinterpret_cast<T*>(ws + p.off_sA), reinterpret_cast<T*>(ws + p.off_sA2)};
   T* sU = reinterpret_cast<T*>(ws + p.off_sU);
-  T* sA = reinterpret_cast<T*>(ws + p.off_sA);
   T* sX = reinterpret_cast<T*>(ws + p.off_sX);
   T* sZ = reinterpret_cast<T*>(ws + p.off_sZ);
   T* sC = reinterpret_cast<T*>(ws + p.off_sC);
   int rc;
+
+  // Weight-gradient GEMMs only feed the optimizer: they run on the side stream beside the dgrad -> BN-backward
+  // chain (one slab, the side stream is in order).  Operand buffers alternate between consecutive layers; the main
+  // stream re-acquires a buffer (waits for the wgrad that read it) before overwriting it.
+  static const bool side_off = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
+  const bool use_side = !side_off && !p.prof.on;
+  if (use_side) {
+    if ((rc = p.side.init())) return rc;
+    if ((rc = p.init_events())) return rc;
+  }
+  for (int i = 0; i < 5; ++i) p.ev_valid[i] = false;
+  auto acquire = [&](int slot) -> int {
+    if (use_side && p.ev_valid[slot]) HIP_CHECK_RET(hipStreamWaitEvent(st, p.ev_done[slot], 0));
+    return MMSKIN_OK;
+  };
+  auto wgrad_async = [&](int slot, const ConvShape& cs, double flops, const T* dout, const T* in, float* dw, int cov,
+                         int civ) -> int {
+    hipStream_t wst = st;
+    if (use_side) {
+      HIP_CHECK_RET(hipEventRecord(p.ev_ready[slot], st));
+      HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.ev_ready[slot], 0));
+      wst = p.side.s;
+    }
+    p.prof.begin(K_WGRAD, st);
+    int r = launch_conv_wgrad<T>(cs, dout, in, slab, dw, wst, cov, civ);
+    p.prof.end(st);
+    if (p.prof.on) { p.prof.flops[K_WGRAD] += flops; p.prof.bytes[K_WGRAD] += conv_bytes(cs, sizeof(T)); }
+    if (r) return r;
+    if (use_side) {
+      HIP_CHECK_RET(hipEventRecord(p.ev_done[slot], p.side.s));
+      p.ev_valid[slot] = true;
+    }
+    return MMSKIN_OK;
+  };
+  int layer_no = 0;
 
   // ---- global average pool <- relu <- norm5: writes the whole of dcat4
   {
@@ -392,16 +447,21 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       const T* a = reinterpret_cast<const T*>(ws + l.a_off);
       const T* u = reinterpret_cast<const T*>(ws + l.u_off);
       ConvShape c1 = {p.N, b.H, b.W, l.Cp, BOTTLE, 1, 1, 1, 0}, c2 = {p.N, b.H, b.W, BOTTLE, G_PAD, 3, 3, 1, 1};
+      const int q = layer_no++ & 1;
+      T* sB = sBq[q];
+      T* sA = sAq[q];
       // gradient of this layer's 32 output channels, padded to the GEMM's 64
+      if ((rc = acquire(q))) return rc;
       PROF(K_BN_BWD, 0.0, 2.0 * b.rows * GROWTH * sizeof(T), slice_pack<T>(dcat + l.Cin, b.Ctot, GROWTH, G_PAD, b.rows, nullptr, nullptr, sB, st));
       // conv2: weight gradient (first 32 rows are real) and data gradient with norm2's mask + sums fused
-      PROF(K_WGRAD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T)), launch_conv_wgrad<T>(c2, sB, u, slab, grads + l.w2_off, st, GROWTH, 0));
+      if ((rc = wgrad_async(q, c2, conv_flops(c2) / 2, sB, u, grads + l.w2_off, GROWTH, 0))) return rc;
       DgradFuse f2;
       f2.x = a; f2.scale = k2; f2.shift = k2 + BOTTLE; f2.partial = partial;
       PROF(K_CONV_DGRAD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T), 1), launch_conv_dgrad<T>(c2, sB, wd + l.wd2, sU, (const T*)nullptr, st, &f2));
       {
         float* cB = cA + BOTTLE; float* cC = cA + 2 * BOTTLE;
         p.prof.begin(K_BN_BWD, st);
+        if ((rc = acquire(2 + q))) return rc;
         rc = bn_bwd_finalize(partial, f2.rows_written, BOTTLE, count, params + l.n2.g_off, k2 + 2 * BOTTLE, k2 + 3 * BOTTLE,
                              grads + l.n2.g_off, grads + l.n2.b_off, cA, cB, cC, red, st);
         if (!rc) rc = bn_bwd_apply<T>(sU, a, nullptr, k2, k2 + BOTTLE, MASK_NONE, cA, cB, cC, sA, nullptr, b.rows, BOTTLE, st);
@@ -410,11 +470,11 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
         if (rc) return rc;
       }
       // conv1: weight gradient, padded input channels dropped by the reduction
-      PROF(K_WGRAD, conv_flops(c1), conv_bytes(c1, sizeof(T)), launch_conv_wgrad<T>(c1, sA, t, slab, grads + l.w1_off, st, 0, l.Cin));
-      // conv1 data gradient with norm1's mask + sums fused (needs the raw prefix as a compact tensor)
-      PROF(K_BN_BWD, 0.0, (double)b.rows * (l.Cin + l.Cp) * sizeof(T), slice_pack<T>(cat, b.Ctot, l.Cin, l.Cp, b.rows, nullptr, nullptr, sX, st));
+      if ((rc = wgrad_async(2 + q, c1, conv_flops(c1), sA, t, grads + l.w1_off, 0, l.Cin))) return rc;
+      // conv1 data gradient with norm1's mask + sums fused: the epilogue reads the raw channel prefix straight from
+      // cat (row pitch Ctot); padded channels [Cin, Cp) have scale = shift = 0, so their mask is false
       DgradFuse f1;
-      f1.x = sX; f1.scale = k1; f1.shift = k1 + l.Cp; f1.partial = partial;
+      f1.x = cat; f1.x_pitch = b.Ctot; f1.scale = k1; f1.shift = k1 + l.Cp; f1.partial = partial;
       PROF(K_CONV_DGRAD, conv_flops(c1), conv_bytes(c1, sizeof(T), 1), launch_conv_dgrad<T>(c1, sA, wd + l.wd1, sZ, (const T*)nullptr, st, &f1));
       {
         float* cB = cA + l.Cp; float* cC = cA + 2 * l.Cp;
@@ -435,8 +495,9 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       const T* tt = reinterpret_cast<const T*>(ws + tr.tt_off);
       const T* pcat = reinterpret_cast<const T*>(ws + pb.cat_off);
       ConvShape ct = {p.N, pb.H, pb.W, tr.C, tr.C / 2, 1, 1, 1, 0};
+      if ((rc = acquire(4))) return rc;
       PROF(K_STEM_MISC, 0.0, 0.0, avgpool2_bwd<T>(dcat, b.Ctot, p.N, pb.H, pb.W, tr.C / 2, sC, st));
-      PROF(K_WGRAD, conv_flops(ct), conv_bytes(ct, sizeof(T)), launch_conv_wgrad<T>(ct, sC, tt, slab, grads + tr.w_off, st));
+      if ((rc = wgrad_async(4, ct, conv_flops(ct), sC, tt, grads + tr.w_off, 0, 0))) return rc;
       DgradFuse f;
       f.x = pcat; f.scale = k; f.shift = k + tr.C; f.partial = partial;
       PROF(K_CONV_DGRAD, conv_flops(ct), conv_bytes(ct, sizeof(T), 1), launch_conv_dgrad<T>(ct, sC, wd + tr.wd, sZ, (const T*)nullptr, st, &f));
@@ -452,8 +513,13 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
     }
   }
 
+  // join: the stem reuses the slab and scratch buffers the side stream has been working on
+  for (int i = 0; i < 5; ++i)
+    if ((rc = acquire(i))) return rc;
+
   // ---- stem: maxpool <- relu <- norm0 <- conv0
   {
+    T* sB = sBq[0];
     DBlock& b = p.blocks[0];
     const size_t rows0 = (size_t)p.N * p.OH0 * p.OW0;
     float* c0 = reinterpret_cast<float*>(ws + p.coef0_off);

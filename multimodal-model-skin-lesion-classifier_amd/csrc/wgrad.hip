@@ -290,7 +290,8 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
 }
 
 #define WG_DIRECT_SPLITS 32   // more splits than this are pre-reduced to WG_GROUPS partial slabs first
-#define WG_GROUPS 16
+#define WG_GROUPS 64        // upper bound; small outputs use more groups so the first stage still fills the chip
+static inline int wg_groups(size_t total) { return total < 32768 ? 64 : (total < 131072 ? 32 : 16); }
 
 template <typename T>
 static size_t slab_bytes(int M, int Cout, int Ktot) {
@@ -345,9 +346,11 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   int nsrc = a.nsplit;
   if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction
     float* slab2 = a.slab + (size_t)a.nsplit * total;
-    if ((rc = partial_reduce<float>(a.slab, nullptr, a.nsplit, (int)total, WG_GROUPS, slab2, st))) return rc;
+    int G = wg_groups(total);
+    if (G > a.nsplit / 2) G = a.nsplit / 2;
+    if ((rc = partial_reduce<float>(a.slab, nullptr, a.nsplit, (int)total, G, slab2, st))) return rc;
     src = slab2;
-    nsrc = WG_GROUPS;
+    nsrc = G;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout,
                      C_for_layout, ntaps_for_layout, cout_valid > 0 ? cout_valid : a.Cout,
