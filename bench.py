@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="resnet50-crossattention", choices=sorted(WORKLOADS))
+    ap.add_argument("--infer", action="store_true", help="time the eval-mode forward only (secondary line; BN folded into the convs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -135,7 +136,7 @@ def main():
     wl = WORKLOADS[args.workload]
     if world > 1:
         dp.broadcast_parameters(model)
-    model.train()
+    model.train(not args.infer)
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     image = torch.randn(B, 3, 224, 224, generator=g).to(device)
@@ -144,7 +145,13 @@ def main():
     crit = nn.CrossEntropyLoss(weight=torch.tensor([0.6, 1.7, 0.9, 1.2, 0.4, 2.1], device=device))
     opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)   # train_pad_20.py:54
 
+    def infer_step():
+        with torch.no_grad():
+            return model(image, meta).sum()
+
     def step():
+        if args.infer:
+            return infer_step()
         opt.zero_grad(set_to_none=True)
         loss = crit(model(image, meta), label)
         loss.backward()
@@ -173,7 +180,7 @@ def main():
     loss_val = float(loss.detach())
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.infer:
         plan = next(iter(model.image_encoder._plans.values()))
         lib = _lib.load()
         lib.mmskin_backbone_profile_enable(plan.handle, 1)
@@ -218,7 +225,7 @@ def main():
         ips = world * B * args.steps / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         out = {
-            "metric": wl["metric"],
+            "metric": wl["metric"] if not args.infer else wl["metric"].replace("fwd+bwd", "eval forward"),
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -230,7 +237,7 @@ def main():
             "loss": round(loss_val, 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.infer:
             out["cpu_baseline"] = cpu_baseline(32, workload=args.workload)
         print(json.dumps(out), flush=True)
     if world > 1:

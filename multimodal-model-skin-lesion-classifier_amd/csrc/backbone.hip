@@ -153,6 +153,13 @@ int build_plan(Plan& p) {
     u.coef_off = carve(cur, 4 * (size_t)u.s.Cout * sizeof(float));
     u.x_off = carve(cur, u.rows() * u.s.Cout * es);
   }
+  for (size_t i = 0; i < p.units.size(); ++i) {   // BatchNorm behind every conv: inference folding / eval coefficients
+    StageDesc& d = p.table_host[i];
+    const Unit& u = p.units[i];
+    d.has_bn = 1;
+    d.bn_g_off = u.g_off; d.bn_b_off = u.b_off; d.bn_rm_off = u.rm_off; d.bn_rv_off = u.rv_off;
+    d.coef_off = (int64_t)u.coef_off;
+  }
   p.off_pool = carve(cur, (size_t)p.N * p.PH * p.PW * 64 * es);
   p.off_idx = carve(cur, (size_t)p.N * p.PH * p.PW * 64);
   // post-activation outputs
@@ -179,6 +186,54 @@ int build_plan(Plan& p) {
   return MMSKIN_OK;
 }
 
+// Inference: eval-mode BatchNorm is folded into the convolutions -- the staged weights carry gamma/sqrt(var+eps)
+// (stage_weights above), the conv epilogue adds the shift, the residual and the ReLU, so no BatchNorm pass and
+// no raw conv output exists (loadImageModelClassifier.py backbones under model.eval(): model_metrics.py:50-62).
+template <typename T>
+int forward_eval(Plan& p, const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
+                 float* features, hipStream_t st) {
+  const float eps = 1e-5f;
+  T* wf = reinterpret_cast<T*>(ws + p.off_wf);
+  int rc, maxC = 64;
+  for (const Unit& u : p.units) maxC = u.s.Cout > maxC ? u.s.Cout : maxC;
+  PROF(K_BN_FWD, 0.0, 0.0, bn_eval_table(p.table_dev, (int)p.units.size(), maxC, params, buffers, ws, eps, st));
+  auto shift_of = [&](const Unit& u) { return reinterpret_cast<const float*>(ws + u.coef_off) + u.s.Cout; };
+  // stem: the 7x7 conv keeps its own BN + ReLU + max-pool kernel (one pass over the largest activation)
+  Unit& u0 = p.units[0];
+  T* img4 = reinterpret_cast<T*>(ws + p.off_img4);
+  if (norm6) PROF(K_STEM_MISC, 0.0, 0.0, stem_pack_u8<T>((const uint8_t*)image, p.N, p.H, p.W, p.Hp, p.Wp, norm6, img4, st));
+  else PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>((const float*)image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
+  T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
+  PROF(K_CONV_FWD, conv_flops(u0.s), conv_bytes(u0.s, sizeof(T)),
+       launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0, nullptr, nullptr, st));
+  const float* c0 = reinterpret_cast<const float*>(ws + u0.coef_off);
+  T* pool = reinterpret_cast<T*>(ws + p.off_pool);
+  PROF(K_STEM_MISC, 0.0, 0.0, stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st));
+  for (Block& b : p.blocks) {
+    const T* in = reinterpret_cast<const T*>(ws + b.in_off);
+    const T* cur = in;
+    const int nu = (int)b.units.size();
+    const T* skip = in;
+    if (b.ds >= 0) {
+      Unit& d = p.units[b.ds];
+      FwdFuse f; f.bias = shift_of(d);
+      T* xd = reinterpret_cast<T*>(ws + d.x_off);
+      PROF(K_CONV_FWD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_fwd<T>(d.s, in, wf + d.wf_off, xd, nullptr, nullptr, st, &f));
+      skip = xd;
+    }
+    for (int i = 0; i < nu; ++i) {
+      Unit& u = p.units[b.units[i]];
+      T* y = reinterpret_cast<T*>(ws + u.y_off);
+      FwdFuse f; f.bias = shift_of(u); f.relu = true;
+      if (i + 1 == nu) f.addend = skip;
+      PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 0), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f));
+      cur = y;
+    }
+  }
+  Unit& last = p.units[p.blocks.back().units.back()];
+  return avgpool_fwd<T>(reinterpret_cast<const T*>(ws + last.y_off), p.N, last.s.OH() * last.s.OW(), last.s.Cout, features, st);
+}
+
 template <typename T>
 int forward_impl(Plan& p, const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
                  float* features, bool training, hipStream_t st) {
@@ -191,7 +246,9 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   if ((rc = p.ensure_table())) return rc;
   // stage weights (stem region needs zeros in its padding taps)
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
-  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st));
+  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st,
+                                           training ? nullptr : buffers, eps));
+  if (!training) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st);
 
   auto bn_coeffs_on = [&](Unit& u, int stat_rows, float* ssum, float* ssq, double* red, hipStream_t s2) -> int {
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);

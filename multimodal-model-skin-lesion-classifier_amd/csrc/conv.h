@@ -38,6 +38,8 @@ struct ConvGemmArgs {
   int ep_x_pitch;          // 0: ep_x rows are Cout elements apart (compact); else the row pitch of ep_x in elements
   const float* ep_scale;   // with ep_shift: mask = (ep_x*scale + shift > 0)   (plain BN+ReLU)
   const float* ep_shift;
+  const float* ep_bias;    // inference: per-output-channel constant added to acc (+ addend) -- the folded BatchNorm shift
+  int ep_relu;             // inference: ReLU on the stored value
   const void* ep_x2;       // second raw tensor (downsample BN of the same block) -> stat_b_*
   float* stat_b_sum;       // = sum v   (again, so the downsample finalize sees the same slab layout)
   float* stat_b_sq;        // = sum v*ep_x2
@@ -71,9 +73,15 @@ struct WgradArgs {
 template <typename T>
 int launch_conv_pipe(ConvGemmArgs& a, hipStream_t st);
 
+// Inference epilogue (eval-mode BatchNorm folded into the conv): out = [relu](acc + bias[c] + addend)
+struct FwdFuse {
+  const float* bias = nullptr;    // [Cout] fp32
+  const void* addend = nullptr;   // optional residual, same layout as out
+  bool relu = false;
+};
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
-                    float* stat_sq, hipStream_t st);
+                    float* stat_sq, hipStream_t st, const FwdFuse* fuse = nullptr);
 // number of stat partial rows the forward launch produces (rows of stat_sum / stat_sq)
 int conv_fwd_stat_rows(const ConvShape& s);
 

@@ -234,6 +234,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const unsigned char* ex_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
   const unsigned char* ex2_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
   const bool mask_from_x = EPI && p.ep_scale != nullptr;
+  const bool has_bias = EPI && p.ep_bias != nullptr;
+  const bool do_relu = EPI && p.ep_relu;
+  float ebias[EPC];
+  if (has_bias) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) ebias[e] = p.ep_bias[n0 + cj * EPC + e];
+  }
   float esc[EPC], esh[EPC];
   if (mask_from_x) {
 #pragma unroll
@@ -286,6 +293,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         ad.from_raw(q_ad[k]);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v.v[e] += ad.v[e];
+      }
+      if (has_bias) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] += ebias[e];
+      }
+      if (do_relu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
       }
       if (my_b) {
         Chunk<T> my;
@@ -385,8 +400,8 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   const bool simple = !(var && !strcmp(var, "pipe"));
   const char* abl = getenv("MMSKIN_CONV_ABLATE");   // timing experiments only
   a.ablate = abl ? atoi(abl) : 0;
-  if (!simple && !a.ep_x) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
-  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x;
+  if (!simple && !a.ep_x && !a.ep_bias && !a.ep_relu) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
+  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
@@ -418,10 +433,11 @@ int stem_conv_stat_rows(int N, int OH, int OW) { return ceil_div(N * OH * OW, CO
 
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
-                    float* stat_sq, hipStream_t st) {
+                    float* stat_sq, hipStream_t st, const FwdFuse* fuse) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
+  if (fuse) { a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->relu ? 1 : 0; }
   a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
   a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;
@@ -513,7 +529,7 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
 }
 
 #define INST(T)                                                                                      \
-  template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t); \
+  template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t, const FwdFuse*); \
   template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t, DgradFuse*);      \
   template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);
 INST(float)

@@ -77,10 +77,18 @@ struct StageDesc {
   int Cout, Cin, taps;
   int stem;          // 1: conv1 7x7 -> virtual [64][8][32] (fwd only)
   int Cout_pad, Cin_pad;   // staged dims (0 = same as Cout / Cin): extra rows / channels are zero
+  // BatchNorm that follows the conv (inference folding): flat param / buffer offsets, coefficient slot in the workspace
+  int64_t bn_g_off, bn_b_off, bn_rm_off, bn_rv_off, coef_off;
+  int has_bn;
 };
+// fold_buffers != nullptr (inference): the forward-staged weights of every layer with has_bn are scaled by
+// gamma / sqrt(running_var + eps) per output channel, so the conv epilogue only adds the shift
 template <typename T>
 int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
-                  T* wdgrad, bool need_dgrad, hipStream_t st);
+                  T* wdgrad, bool need_dgrad, hipStream_t st, const float* fold_buffers = nullptr, float eps = 1e-5f);
+// eval-mode scale / shift of every table layer with has_bn in ONE launch: coef (floats at ws + coef_off) = scale | shift
+int bn_eval_table(const StageDesc* table_dev, int nlayers, int maxC, const float* params, const float* buffers,
+                  unsigned char* ws, float eps, hipStream_t st);
 // dwv[64][8][32] -> OIHW [64][3][7][7]
 int stem_wgrad_unpack(const float* dwv, float* dw, hipStream_t st);
 

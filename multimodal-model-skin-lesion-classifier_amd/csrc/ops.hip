@@ -707,7 +707,8 @@ template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc* __restrict__ table,
                                                                 const float* __restrict__ params,
                                                                 T* __restrict__ wfwd, T* __restrict__ wdgrad,
-                                                                int need_dgrad) {
+                                                                int need_dgrad, const float* __restrict__ fold_buffers,
+                                                                float eps) {
   constexpr int EPC = DT<T>::EPC;
   const StageDesc d = table[blockIdx.y];
   const float* src = params + d.src_off;
@@ -733,8 +734,10 @@ __global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc
       int c0 = (i % cpr) * EPC, ot = i / cpr;
       int t = ot % d.taps, o = ot / d.taps;
       const float* s0 = src + ((size_t)o * d.Cin + c0) * d.taps + t;
+      float fold = 1.f;
+      if (fold_buffers && d.has_bn && o < d.Cout) fold = params[d.bn_g_off + o] / sqrtf(fold_buffers[d.bn_rv_off + o] + eps);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v.v[e] = (o < d.Cout && c0 + e < d.Cin) ? s0[(size_t)e * d.taps] : 0.f;
+      for (int e = 0; e < EPC; ++e) v.v[e] = (o < d.Cout && c0 + e < d.Cin) ? s0[(size_t)e * d.taps] * fold : 0.f;
       v.store(wfwd + d.fwd_off + (size_t)i * EPC);
     } else {                       // dst [c][t][o0..o0+EPC)
       const int opr = Cop / EPC;
@@ -749,12 +752,30 @@ __global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc
 }
 template <typename T>
 int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
-                  T* wdgrad, bool need_dgrad, hipStream_t st) {
+                  T* wdgrad, bool need_dgrad, hipStream_t st, const float* fold_buffers, float eps) {
   int gx = ceil_div(max_elems / DT<T>::EPC, EW_BLOCK * 2);
   if (gx > 64) gx = 64;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(stage_weights_kernel<T>, dim3(gx, nlayers, need_dgrad ? 2 : 1), dim3(EW_BLOCK), 0, st, table_dev,
-                     params, wfwd, wdgrad, need_dgrad ? 1 : 0);
+                     params, wfwd, wdgrad, need_dgrad ? 1 : 0, fold_buffers, eps);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+__global__ void bn_eval_table_kernel(const StageDesc* __restrict__ table, const float* __restrict__ params,
+                                     const float* __restrict__ buffers, unsigned char* ws, float eps) {
+  const StageDesc d = table[blockIdx.y];
+  if (!d.has_bn) return;
+  float* coef = reinterpret_cast<float*>(ws + d.coef_off);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.Cout; c += gridDim.x * blockDim.x) {
+    float sc = params[d.bn_g_off + c] / sqrtf(buffers[d.bn_rv_off + c] + eps);
+    coef[c] = sc;
+    coef[d.Cout + c] = params[d.bn_b_off + c] - buffers[d.bn_rm_off + c] * sc;
+  }
+}
+int bn_eval_table(const StageDesc* table_dev, int nlayers, int maxC, const float* params, const float* buffers,
+                  unsigned char* ws, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_table_kernel, dim3(ceil_div(maxC, 256), nlayers), dim3(256), 0, st, table_dev, params, buffers, ws, eps);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -823,7 +844,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
   template int maxpool_bwd<T>(const T*, const uint8_t*, int, int, int, int, T*, hipStream_t);                   \
   template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \
   template int avgpool_bwd<T>(const float*, int, int, int, T*, hipStream_t);                                    \
-  template int stage_weights<T>(const StageDesc*, int, int, const float*, T*, T*, bool, hipStream_t);           \
+  template int stage_weights<T>(const StageDesc*, int, int, const float*, T*, T*, bool, hipStream_t, const float*, float); \
   template int nchw_to_nhwc<T>(const float*, int, int, int, int, T*, hipStream_t);                              \
   template int nhwc_to_nchw<T>(const T*, int, int, int, int, float*, hipStream_t);
 INST(float)
