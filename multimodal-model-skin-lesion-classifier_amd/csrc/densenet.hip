@@ -28,6 +28,7 @@ struct DLayer {
   int64_t wf1, wd1, wf2, wd2;    // staged element offsets
   size_t t_off, a_off, u_off;    // saved activations (bytes)
   size_t coef1_off, coef2_off;   // floats: 5*Cp | 4*128
+  int tab1;                      // stage-table index of conv1 (norm2 folds into it for inference)
 };
 
 struct DBlock {
@@ -157,6 +158,7 @@ int build_dense_plan(DensePlan& p) {
   }
   for (DBlock& b : p.blocks)
     for (DLayer& l : b.layers) {
+      l.tab1 = (int)p.table_host.size();
       stage(l.w1_off, BOTTLE, l.Cin, 1, BOTTLE, l.Cp, l.wf1, l.wd1);
       stage(l.w2_off, GROWTH, BOTTLE, 9, G_PAD, BOTTLE, l.wf2, l.wd2);
     }
@@ -201,6 +203,12 @@ int build_dense_plan(DensePlan& p) {
       l.u_off = carve(cur, b.rows * BOTTLE * es);
       l.coef1_off = carve(cur, 5 * (size_t)l.Cp * sizeof(float));
       l.coef2_off = carve(cur, 4 * (size_t)BOTTLE * sizeof(float));
+      {
+        StageDesc& d = p.table_host[l.tab1];   // inference: conv1 carries norm2's scale, its epilogue adds shift + ReLU
+        d.has_bn = 1;
+        d.bn_g_off = l.n2.g_off; d.bn_b_off = l.n2.b_off; d.bn_rm_off = l.n2.rm_off; d.bn_rv_off = l.n2.rv_off;
+        d.coef_off = (int64_t)l.coef2_off;
+      }
       ConvShape c1 = {p.N, b.H, b.W, l.Cp, BOTTLE, 1, 1, 1, 0}, c2 = {p.N, b.H, b.W, BOTTLE, G_PAD, 3, 3, 1, 1};
       need_stat((size_t)conv_fwd_stat_rows(c1) * BOTTLE);
       need_stat((size_t)conv_fwd_stat_rows(c2) * G_PAD);
@@ -255,7 +263,9 @@ int dense_forward(DensePlan& p, const void* image, const float* norm6, const flo
   int rc;
   if ((rc = p.ensure_table())) return rc;
   HIP_CHECK_RET(hipMemsetAsync(wf + p.wf0, 0, 64 * 256 * sizeof(T), st));
-  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.table_host.size(), p.max_stage_elems, params, wf, wd, training, st));
+  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.table_host.size(), p.max_stage_elems, params, wf, wd, training, st,
+                                           training ? nullptr : buffers, eps));
+  if (!training) PROF(K_BN_FWD, 0.0, 0.0, bn_eval_table(p.table_dev, (int)p.table_host.size(), BOTTLE, params, buffers, ws, eps, st));
 
   // batch statistics of cat channels [c0, c0+C) of block b -> its mean/var table
   auto table_from_slice = [&](DBlock& b, int c0, int C) -> int {
@@ -313,16 +323,19 @@ int dense_forward(DensePlan& p, const void* image, const float* norm6, const flo
            slice_pack<T>(cat, b.Ctot, l.Cin, l.Cp, b.rows, k1, k1 + l.Cp, t, st));
       // conv1 1x1 -> norm2 -> relu
       ConvShape c1 = {p.N, b.H, b.W, l.Cp, BOTTLE, 1, 1, 1, 0};
+      if (!training) {   // norm2 folded: u = relu(conv1'(t) + shift2) straight from the conv epilogue
+        FwdFuse f; f.bias = k2 + BOTTLE; f.relu = true;
+        PROF(K_CONV_FWD, conv_flops(c1), conv_bytes(c1, sizeof(T)), launch_conv_fwd<T>(c1, t, wf + l.wf1, u, nullptr, nullptr, st, &f));
+      } else {
       PROF(K_CONV_FWD, conv_flops(c1), conv_bytes(c1, sizeof(T)),
            launch_conv_fwd<T>(c1, t, wf + l.wf1, a, training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
+      }
       if (training) {
         PROF(K_BN_FWD, 0.0, 0.0, bn_finalize(stat_sum, stat_sq, conv_fwd_stat_rows(c1), BOTTLE, count, params + l.n2.g_off, params + l.n2.b_off, eps, mom,
                          buffers + l.n2.rm_off, buffers + l.n2.rv_off, k2, k2 + BOTTLE, k2 + 2 * BOTTLE, k2 + 3 * BOTTLE, red, st));
-      } else {
-        PROF(K_BN_FWD, 0.0, 0.0, bn_eval_coeffs(BOTTLE, params + l.n2.g_off, params + l.n2.b_off, buffers + l.n2.rm_off, buffers + l.n2.rv_off, eps, k2, k2 + BOTTLE, st));
+        PROF(K_BN_FWD, 0.0, 2.0 * b.rows * BOTTLE * sizeof(T),
+             bn_apply<T>(a, nullptr, k2, k2 + BOTTLE, nullptr, nullptr, u, b.rows, BOTTLE, true, st));
       }
-      PROF(K_BN_FWD, 0.0, 2.0 * b.rows * BOTTLE * sizeof(T),
-           bn_apply<T>(a, nullptr, k2, k2 + BOTTLE, nullptr, nullptr, u, b.rows, BOTTLE, true, st));
       // conv2 3x3 (32 outputs padded to 64) -> new cat channels + their batch statistics
       ConvShape c2 = {p.N, b.H, b.W, BOTTLE, G_PAD, 3, 3, 1, 1};
       PROF(K_CONV_FWD, conv_flops(c2) / 2, conv_bytes(c2, sizeof(T)),
