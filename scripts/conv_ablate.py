@@ -9,6 +9,8 @@ lib = _lib.load()
 LAYERS = {  # name: (N, Cin, H, W, Cout, k, stride, pad)
     "l1.c2 3x3 64->64 @56": (256, 64, 56, 56, 64, 3, 1, 1),
     "l1.c3 1x1 64->256 @56": (256, 64, 56, 56, 256, 1, 1, 0),
+    "l1.c1 1x1 256->64 @56": (256, 256, 56, 56, 64, 1, 1, 0),
+    "l2.c3 1x1 128->512 @28": (256, 128, 28, 28, 512, 1, 1, 0),
     "l2.c2 3x3 128->128 @28": (256, 128, 28, 28, 128, 3, 1, 1),
     "l3.c1 1x1 1024->256 @14": (256, 1024, 14, 14, 256, 1, 1, 0),
     "l3.c2 3x3 256->256 @14": (256, 256, 14, 14, 256, 3, 1, 1),
