@@ -51,6 +51,13 @@ WORKLOADS = {
                    attention_mecanism="metablock"),
         "flop_per_image": 3 * 6.72e9,   # torchvision densenet169: 3.36 GMAC forward; backward = 2x forward
     },
+    "vgg16-crossattention": {
+        "metric": "images/sec fwd+bwd, VGG-16+crossattention bs=256",
+        "label": "VGG-16 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+        "kw": dict(cnn_model_name="vgg16", text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                   attention_mecanism="crossattention"),
+        "flop_per_image": 3 * 30.9e9,   # torchvision vgg16: 15.47 GMAC forward
+    },
 }
 
 
@@ -181,7 +188,8 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline and not args.infer:
-        plan = next(iter(model.image_encoder._plans.values()))
+        enc = model.image_encoder.features if hasattr(model.image_encoder, "classifier") and hasattr(model.image_encoder.features, "_plans") else model.image_encoder
+        plan = next(iter(enc._plans.values()))
         lib = _lib.load()
         lib.mmskin_backbone_profile_enable(plan.handle, 1)
         nprof = 3

@@ -550,11 +550,13 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   else if (!strcmp(arch, "resnet-50")) a = 50;
   else if (!strcmp(arch, "densenet169")) a = 169;
   else if (!strcmp(arch, "densenet169-features")) a = 1690;   // norm5 feature map, no ReLU / pool (MDNet)
+  else if (!strcmp(arch, "vgg16-features")) a = 16;           // vgg16().features + avgpool -> [N][512][7][7]
   else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
   ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
   ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
   int rc = MMSKIN_OK;
   PlanBase* p = (a == 169 || a == 1690) ? make_densenet_plan(batch, height, width, dtype, a == 1690, &rc)
+                : a == 16               ? make_vgg_plan(batch, height, width, dtype, &rc)
                                         : make_resnet_plan(a, batch, height, width, dtype, &rc);
   if (!p) return rc ? rc : MMSKIN_ERR_ARG;
   mmskin_backbone* h = new mmskin_backbone();
@@ -629,14 +631,14 @@ int mmskin_backbone_unit_info(mmskin_backbone_t h, int index, char* name, int na
 
 int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const float* params, float* buffers,
                             void* workspace, float* features, int training, void* stream) {
-  ARG_CHECK(h && image_nchw && params && buffers && workspace && features, "backbone_forward: null argument");
+  ARG_CHECK(h && image_nchw && params && (buffers || h->plan->buffer_numel == 0) && workspace && features, "backbone_forward: null argument");
   return h->plan->forward(image_nchw, nullptr, params, buffers, (unsigned char*)workspace, features, training != 0,
                           (hipStream_t)stream);
 }
 
 int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, const float* mean_std6, const float* params,
                                float* buffers, void* workspace, float* features, int training, void* stream) {
-  ARG_CHECK(h && image_nhwc && mean_std6 && params && buffers && workspace && features, "backbone_forward_u8: null argument");
+  ARG_CHECK(h && image_nhwc && mean_std6 && params && (buffers || h->plan->buffer_numel == 0) && workspace && features, "backbone_forward_u8: null argument");
   return h->plan->forward(image_nhwc, mean_std6, params, buffers, (unsigned char*)workspace, features, training != 0,
                           (hipStream_t)stream);
 }

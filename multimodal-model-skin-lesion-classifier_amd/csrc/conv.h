@@ -115,6 +115,17 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
                          float* stat_sum, float* stat_sq, hipStream_t st);
 int stem_conv_stat_rows(int N, int OH, int OW);
 
+// VGG's first conv (3x3 s1 p1, Cin=3) as a virtual conv over the zero-bordered NHWC8 image of pack_nhwc8: one tap
+// per kernel row, each reading 32 contiguous elements (4 pixels x 8 ch; 3 x 3 of them carry weights), plus one
+// all-zero tap so K = 4 x 32 = 128.  wv / dwv are [64][4][32].
+template <typename T>
+int launch_vgg_first_conv_fwd(int N, int H, int W, int Hp, int Wp, const T* img8, const T* wv, T* out,
+                              const FwdFuse* fuse, hipStream_t st);
+size_t vgg_first_wgrad_slab_bytes(int N, int H, int W);
+template <typename T>
+int launch_vgg_first_conv_wgrad(int N, int H, int W, int Hp, int Wp, const T* dout, const T* img8, float* slab,
+                                float* dwv, hipStream_t st);
+
 size_t conv_wgrad_slab_bytes(const ConvShape& s);
 // dw: fp32 OIHW [Cout][Cin][kh][kw], reduced over the split slabs.  cout_valid / cin_valid (0 = all): when the
 // GEMM operands carry zero padding (s.Cout / s.Cin rounded up to 64), dw is the UNPADDED

@@ -124,6 +124,28 @@ int avgpool2_fwd(const T* x, int N, int H, int W, int C, T* dst, int pitch, hipS
 template <typename T>
 int avgpool2_bwd(const T* dpool, int pitch, int N, int H, int W, int C, T* dx, hipStream_t st);
 
+// ---- VGG pieces (conv + bias + ReLU stacks with 2x2 max-pools, torchvision vgg16 `features` + `avgpool`)
+// image (fp32 NCHW, or uint8 NHWC with norm6 != nullptr) -> zero-bordered NHWC8 [N][H+2][Wp][8], pixel (h,w) at (h+1, w+1)
+template <typename T>
+int pack_nhwc8(const void* img, const float* norm6, int N, int H, int W, int Hp, int Wp, T* out, hipStream_t st);
+// [64][3][3][3] OIHW fp32 -> virtual-conv operand [64][4][32]: (o, r, s*8 + c); tap 3 and unused slots stay zero
+template <typename T>
+int vgg_stage_first(const float* w, T* wv, hipStream_t st);
+int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st);
+// 2x2 stride-2 max pool (floor), idx = argmax tap 0..3 per element (first max, row-major)
+template <typename T>
+int maxpool2_fwd(const T* x, int N, int H, int W, int C, T* y, uint8_t* idx, hipStream_t st);
+// dz[n][h][w][c] = dpool at the window's argmax where the (post-ReLU) activation y is > 0, else 0
+template <typename T>
+int maxpool2_bwd_relu(const T* dpool, const uint8_t* idx, const T* y, int N, int H, int W, int C, T* dz, hipStream_t st);
+// AdaptiveAvgPool2d(OH, OW): NHWC T -> NCHW fp32, and its backward
+template <typename T>
+int adaptive_avgpool_fwd(const T* x, int N, int H, int W, int C, int OH, int OW, float* out_nchw, hipStream_t st);
+template <typename T>
+int adaptive_avgpool_bwd(const float* dout_nchw, int N, int H, int W, int C, int OH, int OW, T* dx, hipStream_t st);
+// db[c] = sum over rows of partial[r*stride + c]   (conv bias gradient from dgrad-epilogue / column_stats partials)
+int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float* db, double* scratch, hipStream_t st);
+
 // ---- layout converters used by the op-level C ABI (tests / small tensors)
 template <typename T>
 int nchw_to_nhwc(const float* src, int N, int C, int H, int W, T* dst, hipStream_t st);

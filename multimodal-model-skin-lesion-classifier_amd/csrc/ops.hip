@@ -1125,3 +1125,253 @@ int avgpool2_bwd(const T* dpool, int pitch, int N, int H, int W, int C, T* dx, h
   template int avgpool2_bwd<T>(const T*, int, int, int, int, int, T*, hipStream_t);
 INST_SLICE(float)
 INST_SLICE(bf16_t)
+
+// ------------------------------------------------------------------ VGG pieces
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void pack_nhwc8_kernel(const void* __restrict__ img, int u8, Norm6 nm, int N, int H,
+                                                             int W, int Hp, int Wp, T* __restrict__ out) {
+  const size_t total = (size_t)N * Hp * Wp;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
+    int wp = (int)(i % Wp);
+    size_t t = i / Wp;
+    int hp = (int)(t % Hp), n = (int)(t / Hp);
+    int h = hp - 1, w = wp - 1;
+    float v[3] = {0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      if (u8) {
+        const uint8_t* px = reinterpret_cast<const uint8_t*>(img) + (((size_t)n * H + h) * W + w) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)px[c] * nm.a[c] + nm.b[c];
+      } else {
+        const float* f = reinterpret_cast<const float*>(img);
+        size_t base = ((size_t)n * 3 * H + h) * W + w;
+        v[0] = f[base]; v[1] = f[base + (size_t)H * W]; v[2] = f[base + 2 * (size_t)H * W];
+      }
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(out + i * 8) = make_float4(v[0], v[1], v[2], 0.f);
+      *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      uint32_t lo = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+      uint32_t hi = f32_to_bf16_bits(v[2]);
+      *reinterpret_cast<uint4*>(out + i * 8) = make_uint4(lo, hi, 0u, 0u);
+    }
+  }
+}
+template <typename T>
+int pack_nhwc8(const void* img, const float* norm6, int N, int H, int W, int Hp, int Wp, T* out, hipStream_t st) {
+  ARG_CHECK(Hp >= H + 2 && Wp >= W + 4, "pack_nhwc8: bad padded size");
+  Norm6 nm = {};
+  if (norm6)
+    for (int c = 0; c < 3; ++c) {
+      ARG_CHECK(norm6[3 + c] > 0.f, "pack_nhwc8: std[%d] = %f", c, norm6[3 + c]);
+      nm.a[c] = 1.f / (255.f * norm6[3 + c]);
+      nm.b[c] = -norm6[c] / norm6[3 + c];
+    }
+  hipLaunchKernelGGL(pack_nhwc8_kernel<T>, dim3(ew_grid((size_t)N * Hp * Wp)), dim3(EW_BLOCK), 0, st, img, norm6 ? 1 : 0, nm, N,
+                     H, W, Hp, Wp, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ void vgg_stage_first_kernel(const float* __restrict__ w, T* __restrict__ wv) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 64*3*3*3 (o, c, r, s)
+  if (i < 64 * 27) {
+    int o = i / 27, rem = i - o * 27;
+    int c = rem / 9, t = rem - c * 9;
+    int r = t / 3, s2 = t - r * 3;
+    wv[((size_t)o * 4 + r) * 32 + s2 * 8 + c] = from_f32<T>(w[i]);
+  }
+}
+template <typename T>
+int vgg_stage_first(const float* w, T* wv, hipStream_t st) {
+  HIP_CHECK_RET(hipMemsetAsync(wv, 0, 64 * 128 * sizeof(T), st));
+  hipLaunchKernelGGL(vgg_stage_first_kernel<T>, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, w, wv);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+__global__ void vgg_wgrad_unpack_first_kernel(const float* __restrict__ dwv, float* __restrict__ dw) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 64 * 27) {
+    int o = i / 27, rem = i - o * 27;
+    int c = rem / 9, t = rem - c * 9;
+    int r = t / 3, s2 = t - r * 3;
+    dw[i] = dwv[((size_t)o * 4 + r) * 32 + s2 * 8 + c];
+  }
+}
+int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st) {
+  hipLaunchKernelGGL(vgg_wgrad_unpack_first_kernel, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, dwv, dw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_fwd_kernel(const T* __restrict__ x, int H, int W, int CPR,
+                                                               T* __restrict__ y, uint8_t* __restrict__ idx, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const int PH = H / 2, PW = W / 2;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    size_t t = i / CPR;
+    const int pw = (int)(t % PW); size_t t2 = t / PW;
+    const int ph = (int)(t2 % PH);
+    const size_t n = t2 / PH;
+    const size_t C = (size_t)CPR * EPC;
+    const T* p00 = x + (((n * H + 2 * ph) * W) + 2 * pw) * C + (size_t)cc * EPC;
+    Chunk<T> v[4];
+    v[0].load(p00); v[1].load(p00 + C); v[2].load(p00 + (size_t)W * C); v[3].load(p00 + (size_t)W * C + C);
+    Chunk<T> best = v[0];
+    uint8_t bi[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) bi[e] = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        if (v[k].v[e] > best.v[e] || v[k].v[e] != v[k].v[e]) { best.v[e] = v[k].v[e]; bi[e] = (uint8_t)k; }
+    best.store(y + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) idx[i * EPC + e] = bi[e];
+  }
+}
+template <typename T>
+int maxpool2_fwd(const T* x, int N, int H, int W, int C, T* y, uint8_t* idx, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && H >= 2 && W >= 2, "maxpool2_fwd: C=%d %dx%d", C, H, W);
+  const size_t nch = (size_t)N * (H / 2) * (W / 2) * (C / EPC);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, x, H, W, C / EPC, y, idx, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void maxpool2_bwd_relu_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                    const T* __restrict__ y, int H, int W, int CPR,
+                                                                    T* __restrict__ dz, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const int PH = H / 2, PW = W / 2;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    size_t t = i / CPR;          // input pixel (n, h, w)
+    const int w = (int)(t % W); size_t t2 = t / W;
+    const int h = (int)(t2 % H);
+    const size_t n = t2 / H;
+    Chunk<T> out;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) out.v[e] = 0.f;
+    const int ph = h >> 1, pw = w >> 1;
+    if (ph < PH && pw < PW) {    // odd H/W: the last row / column is outside every window
+      const size_t po = (((n * PH + ph) * PW + pw) * CPR + cc) * EPC;
+      const int tap = (h & 1) * 2 + (w & 1);
+      Chunk<T> g, yv;
+      g.load(dpool + po);
+      yv.load(y + i * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        if (idx[po + e] == tap && yv.v[e] > 0.f) out.v[e] = g.v[e];
+    }
+    out.store(dz + i * EPC);
+  }
+}
+template <typename T>
+int maxpool2_bwd_relu(const T* dpool, const uint8_t* idx, const T* y, int N, int H, int W, int C, T* dz, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "maxpool2_bwd_relu: C=%d", C);
+  const size_t nch = (size_t)N * H * W * (C / EPC);
+  hipLaunchKernelGGL(maxpool2_bwd_relu_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dpool, idx, y, H, W, C / EPC, dz, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// adaptive bins as torch: [floor(i*H/OH), ceil((i+1)*H/OH))
+template <typename T>
+__global__ void adaptive_avgpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int OH, int OW,
+                                            float* __restrict__ out) {
+  const size_t total = (size_t)N * C * OH * OW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // thread order follows the NHWC source (channel fastest) for coalesced reads
+    int c = (int)(i % C); size_t t = i / C;
+    int ow = (int)(t % OW); t /= OW;
+    int oh = (int)(t % OH);
+    int n = (int)(t / OH);
+    int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+    int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) s += to_f32(x[(((size_t)n * H + h) * W + w) * C + c]);
+    out[(((size_t)n * C + c) * OH + oh) * OW + ow] = s / (float)((h1 - h0) * (w1 - w0));
+  }
+}
+template <typename T>
+int adaptive_avgpool_fwd(const T* x, int N, int H, int W, int C, int OH, int OW, float* out_nchw, hipStream_t st) {
+  hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel<T>, dim3(ew_grid((size_t)N * C * OH * OW)), dim3(256), 0, st, x, N, H, W, C, OH,
+                     OW, out_nchw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dout, int N, int H, int W, int C, int OH, int OW,
+                                            T* __restrict__ dx) {
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); size_t t = i / C;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H);
+    int n = (int)(t / H);
+    float s = 0.f;
+    // every output bin whose window contains (h, w)
+    for (int oh = (h * OH) / H; oh < OH && (oh * H) / OH <= h; ++oh) {
+      int h0 = (oh * H) / OH, h1 = ((oh + 1) * H + OH - 1) / OH;
+      if (h < h0 || h >= h1) continue;
+      for (int ow = (w * OW) / W; ow < OW && (ow * W) / OW <= w; ++ow) {
+        int w0 = (ow * W) / OW, w1 = ((ow + 1) * W + OW - 1) / OW;
+        if (w < w0 || w >= w1) continue;
+        s += dout[(((size_t)n * C + c) * OH + oh) * OW + ow] / (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dx[i] = from_f32<T>(s);
+  }
+}
+template <typename T>
+int adaptive_avgpool_bwd(const float* dout_nchw, int N, int H, int W, int C, int OH, int OW, T* dx, hipStream_t st) {
+  hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, st, dout_nchw, N, H, W, C,
+                     OH, OW, dx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename IN>
+__global__ void bias_grad_finalize_kernel(const IN* __restrict__ part, int nrows, int stride, int C, float* __restrict__ db) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  double s = 0.0;
+  if (c < C)
+    for (int r = ry; r < nrows; r += 4) s += (double)part[(size_t)r * stride + c];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) db[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
+}
+int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float* db, double* scratch, hipStream_t st) {
+  if (scratch && nrows > 64) {
+    const int G = reduce_groups(nrows);
+    int rc = partial_reduce<double>(partial, nullptr, nrows, stride, G, scratch, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_grad_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, stride, C, db);
+  } else {
+    hipLaunchKernelGGL(bias_grad_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, stride, C, db);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+#define INST_VGG(T)                                                                                         \
+  template int pack_nhwc8<T>(const void*, const float*, int, int, int, int, int, T*, hipStream_t);          \
+  template int vgg_stage_first<T>(const float*, T*, hipStream_t);                                           \
+  template int maxpool2_fwd<T>(const T*, int, int, int, int, T*, uint8_t*, hipStream_t);                    \
+  template int maxpool2_bwd_relu<T>(const T*, const uint8_t*, const T*, int, int, int, int, T*, hipStream_t); \
+  template int adaptive_avgpool_fwd<T>(const T*, int, int, int, int, int, int, float*, hipStream_t);        \
+  template int adaptive_avgpool_bwd<T>(const float*, int, int, int, int, int, int, T*, hipStream_t);
+INST_VGG(float)
+INST_VGG(bf16_t)

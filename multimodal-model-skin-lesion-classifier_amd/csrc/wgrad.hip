@@ -392,7 +392,25 @@ int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout,
   return run_wgrad<T>(a, dwv, 256, 1, st);
 }
 
+size_t vgg_first_wgrad_slab_bytes(int N, int H, int W) {
+  size_t a = slab_bytes<float>(N * H * W, 64, 128), b = slab_bytes<bf16_t>(N * H * W, 64, 128);
+  return a > b ? a : b;
+}
+template <typename T>
+int launch_vgg_first_conv_wgrad(int N, int H, int W, int Hp, int Wp, const T* dout, const T* img8, float* slab,
+                                float* dwv, hipStream_t st) {
+  WgradArgs a = {};
+  a.dy = dout; a.in = img8; a.slab = slab;
+  a.N = N; a.IH = Hp; a.IW = Wp; a.C = 32; a.Cpitch = 8;
+  a.OH = H; a.OW = W; a.Cout = 64; a.Ktot = 128;
+  a.Sy = 1; a.Sx = 1; a.ntaps = 4;
+  a.M = N * H * W;
+  for (int r = 0; r < 4; ++r) { a.offy[r] = (int8_t)(r < 3 ? r : 0); a.offx[r] = 0; }
+  return run_wgrad<T>(a, dwv, 128, 1, st);
+}
+
 #define INST(T)                                                                                   \
+  template int launch_vgg_first_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t); \
   template int launch_conv_wgrad<T>(const ConvShape&, const T*, const T*, float*, float*, hipStream_t, int, int); \
   template int launch_stem_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t);
 INST(float)

@@ -229,7 +229,9 @@ class _FlatBackbone(nn.Module):
         training = self.training
         feats = _BackboneFn.apply(image, self, training, *self.parameters())
         if training:
-            torch._foreach_add_([m.num_batches_tracked for _, m in self._bn_buffers()], 1)
+            counters = [m.num_batches_tracked for _, m in self._bn_buffers()]
+            if counters:
+                torch._foreach_add_(counters, 1)
         return feats
 
 
@@ -343,6 +345,53 @@ class HipDenseNetFeatures(_FlatBackbone):
         self.arch = "densenet169-features"
         self.num_features = _build_densenet169_features(self)
         self._init_flat(compute_dtype)
+
+
+VGG16_CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+
+class HipVGGFeatures(_FlatBackbone):
+    """torchvision `vgg16().features` + `avgpool` on the plan executor (csrc/vgg.hip): children are named by their
+    index in torchvision's Sequential ("0", "2", "5", ...), so keys read `features.0.weight`, ...; returns
+    [N, 512, 7, 7] fp32."""
+
+    def __init__(self, compute_dtype=None):
+        super().__init__()
+        self.arch = "vgg16-features"
+        cin, idx = 3, 0
+        for v in VGG16_CFG:
+            if v == "M":
+                self.add_module(str(idx), nn.MaxPool2d(2, 2))
+                idx += 1
+                continue
+            conv = nn.Conv2d(cin, v, 3, padding=1)
+            nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+            nn.init.constant_(conv.bias, 0)
+            self.add_module(str(idx), conv)
+            self.add_module(str(idx + 1), nn.ReLU(inplace=True))
+            cin, idx = v, idx + 2
+        self._init_flat(compute_dtype)
+
+
+class HipVGG16(nn.Module):
+    """torchvision vgg16 with the last classifier layer dropped (loadImageModelClassifier.py:77-81) -> 4096 features."""
+
+    def __init__(self, compute_dtype=None):
+        super().__init__()
+        from .nn import FusedAway, HipDropout, HipLinear
+        self.features = HipVGGFeatures(compute_dtype)
+        self.avgpool = FusedAway("AdaptiveAvgPool2d(7) (inside the features plan)")
+        self.classifier = nn.Sequential(
+            HipLinear(512 * 7 * 7, 4096, fuse_relu=True), FusedAway("ReLU"), HipDropout(0.5),
+            HipLinear(4096, 4096, fuse_relu=True), FusedAway("ReLU"), HipDropout(0.5))
+        for m in self.classifier:
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+        self.num_features = 4096
+
+    def forward(self, x):
+        return self.classifier(self.features(x).flatten(1))
 
 
 class HipCustomCNN(nn.Sequential):

@@ -158,6 +158,38 @@ class OracleDenseNet169(nn.Module):
         return self.classifier(torch.flatten(F.adaptive_avg_pool2d(f, 1), 1))
 
 
+class OracleVGG16(nn.Module):
+    """torchvision vgg16 (cfg D, no BN) with the last classifier Linear dropped as loadImageModelClassifier.py:77-81
+    does (`classifier = Sequential(*list(classifier.children())[:-1])`) -> 4096 features.  PARITY UNPINNED against
+    torchvision (absent); module indices / state_dict keys follow it."""
+    CFG = (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M")
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in self.CFG:
+            if v == "M":
+                layers.append(nn.MaxPool2d(2, 2))
+            else:
+                layers += [nn.Conv2d(cin, v, 3, padding=1), nn.ReLU(inplace=False)]
+                cin = v
+        self.features = nn.Sequential(*layers)
+        self.avgpool = nn.AdaptiveAvgPool2d((7, 7))
+        self.classifier = nn.Sequential(nn.Linear(512 * 7 * 7, 4096), nn.ReLU(), nn.Dropout(),
+                                        nn.Linear(4096, 4096), nn.ReLU(), nn.Dropout())
+        self.num_features = 4096
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
+
+
 def custom_cnn(common_dim):
     """loadImageModelClassifier.py:50-60."""
     return nn.Sequential(
@@ -193,6 +225,9 @@ def build_image_encoder(name, common_dim, mode):
         net, dim = custom_cnn(common_dim), common_dim
     elif name in RESNET_SPECS:
         net = OracleResNet(name)
+        dim = net.num_features
+    elif name == "vgg16":
+        net = OracleVGG16()
         dim = net.num_features
     elif name == "densenet169":
         net = OracleDenseNet169()

@@ -125,3 +125,15 @@ def test_alternate_model_drop_ins_key_layout():
     import pytest
     with pytest.raises(NotImplementedError):
         MetaNetModel(meta_dim=20, image_encoder="vit_large_patch16_224")
+
+
+def test_vgg16_key_layout_and_plan():
+    """vgg16 branch of the factory (reference :77-81): 4096 features, torchvision key layout, last_layer freeze mode."""
+    from models.loadImageModelClassifier import loadModels
+    from oracle.backbones import OracleVGG16
+    m, dim = loadModels.loadModelImageEncoder("vgg16", 64, "last_layer_unfrozen_weights")
+    assert dim == 4096
+    assert list(m.state_dict().keys()) == list(OracleVGG16().state_dict().keys())
+    assert [k for k, p in m.named_parameters() if p.requires_grad] == ["classifier.3.weight", "classifier.3.bias"]
+    plan = m.features._plan_for(2, 64, 64, None)          # layout check against the C plan happens inside
+    assert plan.out_hw == (7, 7) and plan.feat_dim == 512
