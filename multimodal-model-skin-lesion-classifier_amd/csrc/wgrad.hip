@@ -341,7 +341,7 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   if (rc) return rc;
   size_t total = (size_t)a.Cout * a.Ktot;
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 65536) blocks = 65536;
   const float* src = a.slab;
   int nsrc = a.nsplit;
   if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction
