@@ -69,6 +69,16 @@ int mmskin_backbone_forward(mmskin_backbone_t h, const float* image_nchw, const 
  * kernel, so the host->device copy is 1 byte per value instead of 4.  mean_std6: 6 HOST floats, mean rgb | std rgb. */
 int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, const float* mean_std6, const float* params,
                                float* buffers, void* workspace, float* features, int training, void* stream);
+/* Grad-CAM / Grad-CAM++ consumers (src/services/XAI/models/cam.py:10-60, model_loader.py:36-41) hook the LAST nn.Conv2d
+ * of image_encoder and differentiate the class score w.r.t. its output under model.eval().  With option
+ * "keep_raw_eval" = 1 an eval forward keeps raw conv outputs (BatchNorm is then not folded into the convs);
+ * last_conv_export returns that conv's output [N][C][OH][OW] (fp32) and last_conv_grad the gradient of the pooled
+ * features w.r.t. it for a given d(score)/d(features) [N][C].  ResNet plans only. */
+int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value);
+int mmskin_backbone_last_conv_shape(mmskin_backbone_t h, int* C, int* OH, int* OW);
+int mmskin_backbone_last_conv_export(mmskin_backbone_t h, const void* workspace, float* x_nchw, void* stream);
+int mmskin_backbone_last_conv_grad(mmskin_backbone_t h, const float* dfeatures, const void* workspace, float* dx_nchw,
+                                   void* stream);
 int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,
                              float* param_grads, void* stream);
 

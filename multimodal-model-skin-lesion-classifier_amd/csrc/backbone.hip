@@ -45,6 +45,9 @@ struct Plan : PlanBase {
   int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
               float* features, bool training, hipStream_t st) override;
   int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) override;
+  int last_conv_shape(int* C, int* OH, int* OW) const override;
+  int last_conv_export(const unsigned char* ws, float* x_nchw, hipStream_t st) override;
+  int last_conv_grad(const float* dfeat, const unsigned char* ws, float* dx_nchw, hipStream_t st) override;
   int num_units() const override { return (int)units.size(); }
   int unit_info(int index, std::string* name, int64_t* info12) const override;
 };
@@ -247,8 +250,8 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   // stage weights (stem region needs zeros in its padding taps)
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
   PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st,
-                                           training ? nullptr : buffers, eps));
-  if (!training) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st);
+                                           (training || p.keep_raw_eval) ? nullptr : buffers, eps));
+  if (!training && !p.keep_raw_eval) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st);
 
   auto bn_coeffs_on = [&](Unit& u, int stat_rows, float* ssum, float* ssq, double* red, hipStream_t s2) -> int {
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
@@ -515,6 +518,24 @@ int Plan::backward(const float* dfeat, const float* params, unsigned char* ws, f
   if (dtype == 1) return backward_impl<bf16_t>(*this, dfeat, params, ws, grads, st);
   return backward_impl<float>(*this, dfeat, params, ws, grads, st);
 }
+// torchvision's last nn.Conv2d in module order is the final block's last conv (layerN.k.conv3 / conv2)
+int Plan::last_conv_shape(int* C, int* OH, int* OW) const {
+  const Unit& u = units[blocks.back().units.back()];
+  *C = u.s.Cout; *OH = u.s.OH(); *OW = u.s.OW();
+  return MMSKIN_OK;
+}
+int Plan::last_conv_export(const unsigned char* ws, float* x_nchw, hipStream_t st) {
+  const Unit& u = units[blocks.back().units.back()];
+  if (dtype == 1) return nhwc_to_nchw<bf16_t>(reinterpret_cast<const bf16_t*>(ws + u.x_off), N, u.s.Cout, u.s.OH(), u.s.OW(), x_nchw, st);
+  return nhwc_to_nchw<float>(reinterpret_cast<const float*>(ws + u.x_off), N, u.s.Cout, u.s.OH(), u.s.OW(), x_nchw, st);
+}
+int Plan::last_conv_grad(const float* dfeat, const unsigned char* ws, float* dx_nchw, hipStream_t st) {
+  const Unit& u = units[blocks.back().units.back()];
+  const float* scale = reinterpret_cast<const float*>(ws + u.coef_off);
+  const int HW = u.s.OH() * u.s.OW();
+  if (dtype == 1) return gap_relu_bn_grad<bf16_t>(dfeat, reinterpret_cast<const bf16_t*>(ws + u.y_off), scale, N, HW, u.s.Cout, dx_nchw, st);
+  return gap_relu_bn_grad<float>(dfeat, reinterpret_cast<const float*>(ws + u.y_off), scale, N, HW, u.s.Cout, dx_nchw, st);
+}
 int Plan::unit_info(int index, std::string* name, int64_t* info12) const {
   const Unit& u = units[index];
   // the conv weight is the unit's first parameter; find its name through the param table
@@ -641,6 +662,33 @@ int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, c
   ARG_CHECK(h && image_nhwc && mean_std6 && params && (buffers || h->plan->buffer_numel == 0) && workspace && features, "backbone_forward_u8: null argument");
   return h->plan->forward(image_nhwc, mean_std6, params, buffers, (unsigned char*)workspace, features, training != 0,
                           (hipStream_t)stream);
+}
+
+int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value) {
+  ARG_CHECK(h && key, "backbone_set_option: null argument");
+  if (!strcmp(key, "keep_raw_eval")) { h->plan->keep_raw_eval = value != 0; return MMSKIN_OK; }
+  mmskin_set_error("backbone_set_option: unknown option '%s'", key);
+  return MMSKIN_ERR_ARG;
+}
+int mmskin_backbone_last_conv_shape(mmskin_backbone_t h, int* C, int* OH, int* OW) {
+  ARG_CHECK(h && C && OH && OW, "backbone_last_conv_shape: null argument");
+  int rc = h->plan->last_conv_shape(C, OH, OW);
+  if (rc == MMSKIN_ERR_UNSUPPORTED) mmskin_set_error("backbone_last_conv_*: this plan has no Grad-CAM export");
+  return rc;
+}
+int mmskin_backbone_last_conv_export(mmskin_backbone_t h, const void* workspace, float* x_nchw, void* stream) {
+  ARG_CHECK(h && workspace && x_nchw, "backbone_last_conv_export: null argument");
+  ARG_CHECK(h->plan->keep_raw_eval, "backbone_last_conv_export: set option keep_raw_eval before the forward");
+  int rc = h->plan->last_conv_export((const unsigned char*)workspace, x_nchw, (hipStream_t)stream);
+  if (rc == MMSKIN_ERR_UNSUPPORTED) mmskin_set_error("backbone_last_conv_*: this plan has no Grad-CAM export");
+  return rc;
+}
+int mmskin_backbone_last_conv_grad(mmskin_backbone_t h, const float* dfeatures, const void* workspace, float* dx_nchw,
+                                   void* stream) {
+  ARG_CHECK(h && dfeatures && workspace && dx_nchw, "backbone_last_conv_grad: null argument");
+  int rc = h->plan->last_conv_grad(dfeatures, (const unsigned char*)workspace, dx_nchw, (hipStream_t)stream);
+  if (rc == MMSKIN_ERR_UNSUPPORTED) mmskin_set_error("backbone_last_conv_*: this plan has no Grad-CAM export");
+  return rc;
 }
 
 int mmskin_backbone_backward(mmskin_backbone_t h, const float* dfeatures, const float* params, void* workspace,

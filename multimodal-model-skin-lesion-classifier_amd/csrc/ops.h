@@ -146,6 +146,11 @@ int adaptive_avgpool_bwd(const float* dout_nchw, int N, int H, int W, int C, int
 // db[c] = sum over rows of partial[r*stride + c]   (conv bias gradient from dgrad-epilogue / column_stats partials)
 int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float* db, double* scratch, hipStream_t st);
 
+// Grad-CAM: dx[n][c][hw] (NCHW fp32) = dfeat[n][c] / HW * (y[n][hw][c] > 0) * scale[c]  -- the gradient of the pooled
+// features w.r.t. the raw output of the last conv under eval-mode BatchNorm (y = relu(x*scale + shift + skip), NHWC T)
+template <typename T>
+int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, int HW, int C, float* dx_nchw, hipStream_t st);
+
 // ---- layout converters used by the op-level C ABI (tests / small tensors)
 template <typename T>
 int nchw_to_nhwc(const float* src, int N, int C, int H, int W, T* dst, hipStream_t st);

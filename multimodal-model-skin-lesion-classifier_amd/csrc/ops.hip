@@ -1378,3 +1378,24 @@ int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float
   template int adaptive_avgpool_bwd<T>(const float*, int, int, int, int, int, int, T*, hipStream_t);
 INST_VGG(float)
 INST_VGG(bf16_t)
+
+template <typename T>
+__global__ void gap_relu_bn_grad_kernel(const float* __restrict__ dfeat, const T* __restrict__ y, const float* __restrict__ scale,
+                                        int N, int HW, int C, float* __restrict__ dx) {
+  const size_t total = (size_t)N * HW * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); size_t t = i / C;      // NHWC source order
+    int hw = (int)(t % HW);
+    int n = (int)(t / HW);
+    float g = to_f32(y[i]) > 0.f ? dfeat[(size_t)n * C + c] * scale[c] / (float)HW : 0.f;
+    dx[((size_t)n * C + c) * HW + hw] = g;
+  }
+}
+template <typename T>
+int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, int HW, int C, float* dx_nchw, hipStream_t st) {
+  hipLaunchKernelGGL(gap_relu_bn_grad_kernel<T>, dim3(ew_grid((size_t)N * HW * C)), dim3(256), 0, st, dfeat, y, scale, N, HW, C, dx_nchw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template int gap_relu_bn_grad<float>(const float*, const float*, const float*, int, int, int, float*, hipStream_t);
+template int gap_relu_bn_grad<bf16_t>(const float*, const bf16_t*, const float*, int, int, int, float*, hipStream_t);

@@ -95,6 +95,12 @@ struct PlanBase {
   virtual int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
                       float* features, bool training, hipStream_t st) = 0;
   virtual int backward(const float* dfeat, const float* params, unsigned char* ws, float* grads, hipStream_t st) = 0;
+  // Grad-CAM support: the raw output of the network's last nn.Conv2d and d(features)/d(that output)
+  // for an eval-mode forward that kept raw conv outputs (option "keep_raw_eval"); plans without it: unsupported
+  bool keep_raw_eval = false;
+  virtual int last_conv_shape(int*, int*, int*) const { return MMSKIN_ERR_UNSUPPORTED; }
+  virtual int last_conv_export(const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }
+  virtual int last_conv_grad(const float*, const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }
   // per-unit introspection (tests / diagnostics); plans without it report zero units
   virtual int num_units() const { return 0; }
   virtual int unit_info(int, std::string*, int64_t*) const { return MMSKIN_ERR_UNSUPPORTED; }

@@ -34,6 +34,10 @@ _SIGNATURES = {
     "mmskin_backbone_workspace_bytes": (_i64, [_P]),
     "mmskin_backbone_feature_dim": (_i, [_P]),
     "mmskin_backbone_feature_hw": (_i, [_P, _P, _P]),
+    "mmskin_backbone_set_option": (_i, [_P, ctypes.c_char_p, _i]),
+    "mmskin_backbone_last_conv_shape": (_i, [_P, _P, _P, _P]),
+    "mmskin_backbone_last_conv_export": (_i, [_P, _P, _P, _P]),
+    "mmskin_backbone_last_conv_grad": (_i, [_P, _P, _P, _P, _P]),
     "mmskin_mdnet_fuse_forward": (_i, [_P] * 5 + [_i64, _i, _P]),
     "mmskin_mdnet_fuse_backward": (_i, [_P] * 9 + [_i64, _i, _P]),
     "mmskin_backbone_profile_enable": (_i, [_P, _i]),

@@ -64,6 +64,11 @@ class _Plan:
         self.ws_bytes = lib.mmskin_backbone_workspace_bytes(h)
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device) if device is not None else None
 
+    def last_conv_shape(self):
+        c, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        call("mmskin_backbone_last_conv_shape", self.handle, ctypes.byref(c), ctypes.byref(oh), ctypes.byref(ow))
+        return c.value, oh.value, ow.value
+
     def tensor_table(self, kind):
         lib = _lib.load()
         out = []
@@ -133,6 +138,27 @@ class _BackboneFn(torch.autograd.Function):
             else:
                 p.grad.add_(view)
         return (None, None, None) + (None,) * len(module._layout)
+
+
+class _CamTailFn(torch.autograd.Function):
+    """features as a function of the last conv's raw output (eval-mode BN + skip + ReLU + global average pool), so that
+    `torch.autograd.grad(score, activations)` of the reference's Grad-CAM code (XAI/models/cam.py:38-43) reaches the
+    activations its forward hook captured.  The forward value was already computed by the plan."""
+
+    @staticmethod
+    def forward(ctx, acts, plan, feats):
+        ctx.plan = plan
+        return feats.clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dfeat):
+        plan = ctx.plan
+        dfeat = dfeat.float().contiguous()
+        c, oh, ow = plan.last_conv_shape()
+        dx = torch.empty((dfeat.shape[0], c, oh, ow), device=dfeat.device, dtype=torch.float32)
+        call("mmskin_backbone_last_conv_grad", plan.handle, ptr(dfeat), ptr(plan.workspace), ptr(dx), stream())
+        return dx, None, None
 
 
 class _FlatBackbone(nn.Module):
@@ -223,9 +249,42 @@ class _FlatBackbone(nn.Module):
             self._plans[key] = plan
         return plan
 
+    def _hooked_last_conv(self):
+        """The module Grad-CAM code finds with `find_last_conv` (XAI/models/model_loader.py:36-41) when it carries hooks."""
+        last = None
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                last = m
+        return last if last is not None and len(last._forward_hooks) > 0 else None
+
+    def _forward_with_cam_hooks(self, image, conv):
+        if self.training or self.arch not in RESNET_DEPTHS:
+            raise _lib.MMSkinError("forward hooks on the last conv (Grad-CAM) are supported for ResNet encoders in eval mode")
+        image = image.detach()
+        n, h, w = (image.shape[0], image.shape[1], image.shape[2]) if image.dtype == torch.uint8 else \
+            (image.shape[0], image.shape[2], image.shape[3])
+        plan = self._plan_for(n, h, w, image.device)
+        call("mmskin_backbone_set_option", plan.handle, b"keep_raw_eval", 1)
+        try:
+            feats = _BackboneFn.apply(image, self, False, *[p.detach() for p in self.parameters()])
+            c, oh, ow = plan.last_conv_shape()
+            acts = torch.empty((n, c, oh, ow), device=image.device, dtype=torch.float32)
+            call("mmskin_backbone_last_conv_export", plan.handle, ptr(plan.workspace), ptr(acts), stream())
+        finally:
+            call("mmskin_backbone_set_option", plan.handle, b"keep_raw_eval", 0)
+        acts.requires_grad_(True)
+        for hook in list(conv._forward_hooks.values()):
+            out = hook(conv, (None,), acts)
+            if out is not None:
+                acts = out
+        return _CamTailFn.apply(acts, plan, feats)
+
     def forward(self, image):
         if not self._packed():
             self._repack()
+        conv = self._hooked_last_conv()
+        if conv is not None:
+            return self._forward_with_cam_hooks(image, conv)
         training = self.training
         feats = _BackboneFn.apply(image, self, training, *self.parameters())
         if training:

@@ -280,3 +280,44 @@ def test_uint8_nhwc_input_path(arch):
     assert torch.allclose(a, c, rtol=1e-3, atol=1e-4), (a - c).abs().max()
     with pytest.raises(Exception):
         hip.image_encoder(torch.zeros(2, 3, 64, 64, dtype=torch.uint8, device=DEV))     # uint8 must be NHWC
+
+
+def test_gradcam_consumer_on_last_conv():
+    """the reference's Grad-CAM++ (src/services/XAI/models/cam.py:10-60) hooks the last nn.Conv2d of
+    image_encoder (model_loader.py:36-41), runs model(image, metadata) in eval mode and takes
+    autograd.grad(score, activations, retain_graph=True, create_graph=True).  The same calls must work on the HIP
+    model and give the oracle's activations, gradients and CAM."""
+    def find_last_conv(module):
+        last = None
+        for m in module.modules():
+            if isinstance(m, nn.Conv2d):
+                last = m
+        return last
+
+    def cam_pp(model, image, meta, target):
+        store = {}
+        h = find_last_conv(model.image_encoder).register_forward_hook(lambda mod, i, o: store.__setitem__("a", o))
+        image.requires_grad_(True)
+        out = model(image, meta)
+        score = out[:, target]
+        acts = store["a"]
+        grads = torch.autograd.grad(score.sum(), acts, retain_graph=True, create_graph=True)[0]
+        g2, g3 = grads ** 2, grads ** 3
+        alpha = g2 / (2 * g2 + (acts * g3).sum(dim=(2, 3), keepdim=True) + 1e-8)
+        weights = (alpha * torch.relu(grads)).sum(dim=(2, 3), keepdim=True)
+        cam = torch.relu((weights * acts).sum(dim=1, keepdim=True))
+        h.remove()
+        return out.detach().cpu(), acts.detach().cpu(), grads.detach().cpu(), cam.detach().cpu()
+
+    kw = dict(SMALL, cnn_model_name="resnet-18", attention_mecanism="concatenation")
+    cpu, hip = build_pair("fp32", **kw)
+    cpu.eval(); hip.eval()
+    img, meta, _ = det_inputs(3, 64, 20, 6)
+    o_c, a_c, g_c, cam_c = cam_pp(cpu, img.clone(), meta, 2)
+    o_h, a_h, g_h, cam_h = cam_pp(hip, img.clone().to(DEV), meta.to(DEV), 2)
+    assert a_h.shape == a_c.shape == (3, 512, 2, 2)
+    assert torch.allclose(o_h, o_c, rtol=1e-3, atol=1e-4)
+    assert rel_err(a_h, a_c) < 1e-4 and rel_err(g_h, g_c) < 1e-3 and rel_err(cam_h, cam_c) < 1e-3
+    # without hooks the folded inference path is used again and gives the same logits
+    with torch.no_grad():
+        assert torch.allclose(hip(img.to(DEV), meta.to(DEV)).cpu(), o_c, rtol=1e-3, atol=1e-4)
