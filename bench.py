@@ -51,6 +51,13 @@ WORKLOADS = {
                    attention_mecanism="metablock"),
         "flop_per_image": 3 * 6.72e9,   # torchvision densenet169: 3.36 GMAC forward; backward = 2x forward
     },
+    "mobilenetv2-crossattention": {
+        "metric": "images/sec fwd+bwd, MobileNet-V2+crossattention bs=256",
+        "label": "MobileNet-V2 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+        "kw": dict(cnn_model_name="mobilenet-v2", text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                   attention_mecanism="crossattention"),
+        "flop_per_image": 3 * 0.6e9,   # torchvision mobilenet_v2: 0.30 GMAC forward
+    },
     "vgg16-crossattention": {
         "metric": "images/sec fwd+bwd, VGG-16+crossattention bs=256",
         "label": "VGG-16 + one-hot(20) + crossattention, 224x224, train step incl. Adam",

@@ -572,12 +572,14 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   else if (!strcmp(arch, "densenet169")) a = 169;
   else if (!strcmp(arch, "densenet169-features")) a = 1690;   // norm5 feature map, no ReLU / pool (MDNet)
   else if (!strcmp(arch, "vgg16-features")) a = 16;           // vgg16().features + avgpool -> [N][512][7][7]
+  else if (!strcmp(arch, "mobilenet-v2")) a = 2;
   else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
   ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
   ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
   int rc = MMSKIN_OK;
   PlanBase* p = (a == 169 || a == 1690) ? make_densenet_plan(batch, height, width, dtype, a == 1690, &rc)
                 : a == 16               ? make_vgg_plan(batch, height, width, dtype, &rc)
+                : a == 2                ? make_mobilenet_plan(batch, height, width, dtype, &rc)
                                         : make_resnet_plan(a, batch, height, width, dtype, &rc);
   if (!p) return rc ? rc : MMSKIN_ERR_ARG;
   mmskin_backbone* h = new mmskin_backbone();

@@ -120,11 +120,12 @@ int stem_conv_stat_rows(int N, int OH, int OW);
 // all-zero tap so K = 4 x 32 = 128.  wv / dwv are [64][4][32].
 template <typename T>
 int launch_vgg_first_conv_fwd(int N, int H, int W, int Hp, int Wp, const T* img8, const T* wv, T* out,
-                              const FwdFuse* fuse, hipStream_t st);
-size_t vgg_first_wgrad_slab_bytes(int N, int H, int W);
+                              const FwdFuse* fuse, hipStream_t st, int stride = 1, float* stat_sum = nullptr,
+                              float* stat_sq = nullptr);
+size_t vgg_first_wgrad_slab_bytes(int N, int H, int W);   // H, W = OUTPUT size
 template <typename T>
 int launch_vgg_first_conv_wgrad(int N, int H, int W, int Hp, int Wp, const T* dout, const T* img8, float* slab,
-                                float* dwv, hipStream_t st);
+                                float* dwv, hipStream_t st, int stride = 1);
 
 size_t conv_wgrad_slab_bytes(const ConvShape& s);
 // dw: fp32 OIHW [Cout][Cin][kh][kw], reduced over the split slabs.  cout_valid / cin_valid (0 = all): when the

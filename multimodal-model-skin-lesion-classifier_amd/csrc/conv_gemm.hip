@@ -530,25 +530,28 @@ int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, c
 
 template <typename T>
 int launch_vgg_first_conv_fwd(int N, int H, int W, int Hp, int Wp, const T* img8, const T* wv, T* out,
-                              const FwdFuse* fuse, hipStream_t st) {
-  ARG_CHECK(Hp >= H + 2 && Wp >= W + 4, "vgg first conv: padded image too small");
+                              const FwdFuse* fuse, hipStream_t st, int stride, float* stat_sum, float* stat_sq) {
+  // H, W: input image size; output = (H + 2 - 3) / stride + 1
+  ARG_CHECK(Hp >= H + 2 && Wp >= W + 4 && (stride == 1 || stride == 2), "first 3x3 conv: padded image too small / stride");
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
   ConvGemmArgs a = {};
   a.in = img8; a.w = wv; a.out = out;
+  a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = 64;
   if (fuse) { a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->relu ? 1 : 0; }
   a.N = N; a.IH = Hp; a.IW = Wp; a.C = 32; a.Cpitch = 8;
   a.Cout = 64; a.wrow = 4 * 32;
-  a.Sy = 1; a.Sx = 1; a.OS = 1;
-  a.OHf = H; a.OWf = W;
+  a.Sy = stride; a.Sx = stride; a.OS = 1;
+  a.OHf = OH; a.OWf = OW;
   a.ncls = 1;
   TapClass& c = a.cls[0];
-  c.a_dim = H; c.b_dim = W; c.ph = 0; c.pw = 0; c.ntaps = 4;
+  c.a_dim = OH; c.b_dim = OW; c.ph = 0; c.pw = 0; c.ntaps = 4;
   for (int r = 0; r < 4; ++r) { c.offy[r] = (int8_t)(r < 3 ? r : 0); c.offx[r] = 0; c.wtap[r] = (int8_t)r; }
   finish_classes(a);
   return dispatch_conv_gemm<T>(a, st);
 }
 
 #define INST(T)                                                                                      \
-  template int launch_vgg_first_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, const FwdFuse*, hipStream_t); \
+  template int launch_vgg_first_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, const FwdFuse*, hipStream_t, int, float*, float*); \
   template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t, const FwdFuse*); \
   template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t, DgradFuse*);      \
   template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);

@@ -21,7 +21,8 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
 template <typename T>
 int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
              const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st,
-             uint8_t* mask_bits = nullptr);   // optional: one byte per 16-byte chunk, bit e = (y[e] > 0)
+             uint8_t* mask_bits = nullptr,    // optional: one byte per 16-byte chunk, bit e = (y[e] > 0)
+             float relu_cap = 0.f);           // > 0: ReLU6-style clamp min(relu(.), cap)  (MobileNet)
 // Column partial sums of an arbitrary NHWC tensor (used where no conv epilogue produced them).
 template <typename T>
 int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq, int* nrows_out,
@@ -29,7 +30,7 @@ int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq
 int column_stats_rows(size_t rows, int C);
 
 // ---- BatchNorm backward
-enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2 };
+enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2, MASK_FROM_Y6 = 3 };   // Y6: 0 < y < 6 (ReLU6)
 int bn_bwd_partial_rows(size_t rows, int C);  // upper bound over dtypes (for sizing only)
 // partial[blk][0][C] = sum dz, partial[blk][1][C] = sum dz*x   with dz = dy * mask
 template <typename T>
@@ -130,8 +131,8 @@ template <typename T>
 int pack_nhwc8(const void* img, const float* norm6, int N, int H, int W, int Hp, int Wp, T* out, hipStream_t st);
 // [64][3][3][3] OIHW fp32 -> virtual-conv operand [64][4][32]: (o, r, s*8 + c); tap 3 and unused slots stay zero
 template <typename T>
-int vgg_stage_first(const float* w, T* wv, hipStream_t st);
-int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st);
+int vgg_stage_first(const float* w, T* wv, hipStream_t st, int cout = 64);   // cout <= 64 real output channels
+int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st, int cout = 64);
 // 2x2 stride-2 max pool (floor), idx = argmax tap 0..3 per element (first max, row-major)
 template <typename T>
 int maxpool2_fwd(const T* x, int N, int H, int W, int C, T* y, uint8_t* idx, hipStream_t st);
@@ -150,6 +151,21 @@ int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float
 // features w.r.t. the raw output of the last conv under eval-mode BatchNorm (y = relu(x*scale + shift + skip), NHWC T)
 template <typename T>
 int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, int HW, int C, float* dx_nchw, hipStream_t st);
+
+// ---- depthwise 3x3 convolution (pad 1, stride 1 or 2) on NHWC T with C a multiple of the chunk width (MobileNet)
+// w_tc: staged weights [9][C] (tap-major) in T
+template <typename T>
+int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st);
+template <typename T>
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st);
+template <typename T>
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st);
+// dw[c][tap] (OIHW [C][1][3][3], first Cv channels written) = sum over output pixels of dout * shifted input;
+// partial: scratch of dwconv3_wgrad_partial_floats() floats
+size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride);
+template <typename T>
+int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
+                  int Cv, hipStream_t st);
 
 // ---- layout converters used by the op-level C ABI (tests / small tensors)
 template <typename T>

@@ -231,7 +231,8 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ rscale,
                                                             const float* __restrict__ rshift, T* __restrict__ y,
-                                                            uint8_t* __restrict__ mask_bits, size_t nchunks, int CPR) {
+                                                            uint8_t* __restrict__ mask_bits, size_t nchunks, int CPR,
+                                                            float relu_cap) {
   constexpr int EPC = DT<T>::EPC;
   for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
     int c0 = (int)(i % CPR) * EPC;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
       if (RES == 1) t += r.v[e];
       if (RES == 2) t += r.v[e] * rscale[c0 + e] + rshift[c0 + e];
       if (RELU) t = fmaxf(t, 0.f);
+      if (RELU && relu_cap > 0.f) t = fminf(t, relu_cap);
       v.v[e] = t;
       bits |= (from_f32<T>(t) != 0 && t > 0.f ? 1u : 0u) << e;   // bit = (stored y > 0)
     }
@@ -256,13 +258,14 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
 
 template <typename T>
 int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
-             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st, uint8_t* mask_bits) {
+             const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st, uint8_t* mask_bits,
+             float relu_cap) {
   constexpr int EPC = DT<T>::EPC;
   ARG_CHECK(C % EPC == 0, "bn_apply: C=%d", C);
   size_t nch = rows * (C / EPC);
   int grid = ew_grid(nch);
   int mode = res ? (rscale ? 2 : 1) : 0;
-#define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC)
+#define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC, relu_cap)
   if (relu) { if (mode == 2) LAUNCH(true, 2); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 0); }
   else { if (mode == 2) LAUNCH(false, 2); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 0); }
 #undef LAUNCH
@@ -329,6 +332,12 @@ __device__ __forceinline__ void masked_dy(Chunk<T>& dz, const Chunk<T>& xv, cons
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
       if (!(yv.v[e] > 0.f)) dz.v[e] = 0.f;
+  } else if (MODE == MASK_FROM_Y6) {
+    Chunk<T> yv;
+    yv.load(ymask + off);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(yv.v[e] > 0.f && yv.v[e] < 6.f)) dz.v[e] = 0.f;
   }
 }
 
@@ -372,6 +381,7 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
 #define LAUNCH(M) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, M>), dim3(g.gx, g.gy), dim3(256), 0, st, dy, x, ymask, scale, shift, rows, C, g, partial)
   if (mask_mode == MASK_FROM_X) LAUNCH(MASK_FROM_X);
   else if (mask_mode == MASK_FROM_Y) LAUNCH(MASK_FROM_Y);
+  else if (mask_mode == MASK_FROM_Y6) LAUNCH(MASK_FROM_Y6);
   else LAUNCH(MASK_NONE);
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
@@ -459,6 +469,7 @@ int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, co
 #define LAUNCH(M, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, W>), dim3(grid), dim3(EW_BLOCK), 0, st, dy, x, ymask, scale, shift, cA, cB, cC, dx, dz_out, nch, C / EPC)
   if (mask_mode == MASK_FROM_X) { if (dz_out) LAUNCH(MASK_FROM_X, true); else LAUNCH(MASK_FROM_X, false); }
   else if (mask_mode == MASK_FROM_Y) { if (dz_out) LAUNCH(MASK_FROM_Y, true); else LAUNCH(MASK_FROM_Y, false); }
+  else if (mask_mode == MASK_FROM_Y6) { if (dz_out) LAUNCH(MASK_FROM_Y6, true); else LAUNCH(MASK_FROM_Y6, false); }
   else { if (dz_out) LAUNCH(MASK_NONE, true); else LAUNCH(MASK_NONE, false); }
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
@@ -837,7 +848,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
 }
 
 #define INST(T)                                                                                               \
-  template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t, uint8_t*); \
+  template int bn_apply<T>(const T*, const T*, const float*, const float*, const float*, const float*, T*, size_t, int, bool, hipStream_t, uint8_t*, float); \
   template int column_stats<T>(const T*, size_t, int, float*, float*, int*, hipStream_t);                       \
   template int bn_bwd_reduce<T>(const T*, const T*, const T*, const float*, const float*, int, size_t, int, float*, int*, hipStream_t); \
   template int bn_bwd_apply<T>(const T*, const T*, const T*, const float*, const float*, int, const float*, const float*, const float*, T*, T*, size_t, int, hipStream_t); \
@@ -1178,9 +1189,9 @@ int pack_nhwc8(const void* img, const float* norm6, int N, int H, int W, int Hp,
 }
 
 template <typename T>
-__global__ void vgg_stage_first_kernel(const float* __restrict__ w, T* __restrict__ wv) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 64*3*3*3 (o, c, r, s)
-  if (i < 64 * 27) {
+__global__ void vgg_stage_first_kernel(const float* __restrict__ w, T* __restrict__ wv, int cout) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over cout*3*3*3 (o, c, r, s)
+  if (i < cout * 27) {
     int o = i / 27, rem = i - o * 27;
     int c = rem / 9, t = rem - c * 9;
     int r = t / 3, s2 = t - r * 3;
@@ -1188,23 +1199,23 @@ __global__ void vgg_stage_first_kernel(const float* __restrict__ w, T* __restric
   }
 }
 template <typename T>
-int vgg_stage_first(const float* w, T* wv, hipStream_t st) {
+int vgg_stage_first(const float* w, T* wv, hipStream_t st, int cout) {
   HIP_CHECK_RET(hipMemsetAsync(wv, 0, 64 * 128 * sizeof(T), st));
-  hipLaunchKernelGGL(vgg_stage_first_kernel<T>, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, w, wv);
+  hipLaunchKernelGGL(vgg_stage_first_kernel<T>, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, w, wv, cout);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
-__global__ void vgg_wgrad_unpack_first_kernel(const float* __restrict__ dwv, float* __restrict__ dw) {
+__global__ void vgg_wgrad_unpack_first_kernel(const float* __restrict__ dwv, float* __restrict__ dw, int cout) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 64 * 27) {
+  if (i < cout * 27) {
     int o = i / 27, rem = i - o * 27;
     int c = rem / 9, t = rem - c * 9;
     int r = t / 3, s2 = t - r * 3;
     dw[i] = dwv[((size_t)o * 4 + r) * 32 + s2 * 8 + c];
   }
 }
-int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st) {
-  hipLaunchKernelGGL(vgg_wgrad_unpack_first_kernel, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, dwv, dw);
+int vgg_wgrad_unpack_first(const float* dwv, float* dw, hipStream_t st, int cout) {
+  hipLaunchKernelGGL(vgg_wgrad_unpack_first_kernel, dim3(ceil_div(64 * 27, 256)), dim3(256), 0, st, dwv, dw, cout);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1371,7 +1382,7 @@ int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float
 
 #define INST_VGG(T)                                                                                         \
   template int pack_nhwc8<T>(const void*, const float*, int, int, int, int, int, T*, hipStream_t);          \
-  template int vgg_stage_first<T>(const float*, T*, hipStream_t);                                           \
+  template int vgg_stage_first<T>(const float*, T*, hipStream_t, int);                                      \
   template int maxpool2_fwd<T>(const T*, int, int, int, int, T*, uint8_t*, hipStream_t);                    \
   template int maxpool2_bwd_relu<T>(const T*, const uint8_t*, const T*, int, int, int, int, T*, hipStream_t); \
   template int adaptive_avgpool_fwd<T>(const T*, int, int, int, int, int, int, float*, hipStream_t);        \
@@ -1399,3 +1410,219 @@ int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, 
 }
 template int gap_relu_bn_grad<float>(const float*, const float*, const float*, int, int, int, float*, hipStream_t);
 template int gap_relu_bn_grad<bf16_t>(const float*, const bf16_t*, const float*, int, int, int, float*, hipStream_t);
+
+// ------------------------------------------------------------------ depthwise 3x3 (MobileNet)
+template <typename T>
+__global__ void dw_stage_weights_kernel(const float* __restrict__ w, int C, int Cp, T* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 9 * Cp: (tap, c)
+  if (i < 9 * Cp) {
+    int t = i / Cp, c = i - t * Cp;
+    out[i] = from_f32<T>(c < C ? w[(size_t)c * 9 + t] : 0.f);
+  }
+}
+template <typename T>
+int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st) {
+  hipLaunchKernelGGL(dw_stage_weights_kernel<T>, dim3(ceil_div(9 * Cp, 256)), dim3(256), 0, st, w_oihw, C, Cp, w_tc);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, int H, int W,
+                                                              int CPR, int stride, int OH, int OW, T* __restrict__ out,
+                                                              size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const size_t C = (size_t)CPR * EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    size_t t = i / CPR;
+    const int ox = (int)(t % OW); size_t t2 = t / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t n = t2 / OH;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * stride - 1 + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int ix = ox * stride - 1 + q;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        Chunk<T> v, wv;
+        v.load(in + ((n * H + iy) * W + ix) * C + (size_t)cc * EPC);
+        wv.load(w + (size_t)(r * 3 + q) * C + (size_t)cc * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += v.v[e] * wv.v[e];
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
+    o.store(out + i * EPC);
+  }
+}
+template <typename T>
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_fwd: C=%d stride=%d", C, stride);
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  const size_t nch = (size_t)N * OH * OW * (C / EPC);
+  hipLaunchKernelGGL(dwconv3_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, in, w_tc, H, W, C / EPC, stride, OH, OW, out, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __restrict__ dout, const T* __restrict__ w, int H, int W,
+                                                                int CPR, int stride, int OH, int OW, T* __restrict__ din,
+                                                                size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const size_t C = (size_t)CPR * EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    size_t t = i / CPR;
+    const int ix = (int)(t % W); size_t t2 = t / W;
+    const int iy = (int)(t2 % H);
+    const size_t n = t2 / H;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ty = iy + 1 - r;
+      if (ty < 0 || ty % stride != 0) continue;
+      const int oy = ty / stride;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int tx = ix + 1 - q;
+        if (tx < 0 || tx % stride != 0) continue;
+        const int ox = tx / stride;
+        if (ox >= OW) continue;
+        Chunk<T> g, wv;
+        g.load(dout + ((n * OH + oy) * OW + ox) * C + (size_t)cc * EPC);
+        wv.load(w + (size_t)(r * 3 + q) * C + (size_t)cc * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += g.v[e] * wv.v[e];
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
+    o.store(din + i * EPC);
+  }
+}
+template <typename T>
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_dgrad: C=%d stride=%d", C, stride);
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  const size_t nch = (size_t)N * H * W * (C / EPC);
+  hipLaunchKernelGGL(dwconv3_dgrad_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dout, w_tc, H, W, C / EPC, stride, OH, OW, din, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// weight gradient: blockIdx.x = strip of output pixels, blockIdx.y = group of 32 chunk columns; 8 pixel lanes per block
+#define DWW_COLS 32
+#define DWW_LANES 8
+static inline int dww_strips(size_t opix) {
+  size_t s = (opix + 2047) / 2048;
+  if (s < 1) s = 1;
+  if (s > 4096) s = 4096;
+  return (int)s;
+}
+size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride) {
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  return (size_t)dww_strips((size_t)N * OH * OW) * 9 * C;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const T* __restrict__ dout, const T* __restrict__ in, int H, int W,
+                                                           int CPR, int stride, int OH, int OW, size_t opix, size_t per_strip,
+                                                           float* __restrict__ partial) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[DWW_LANES][DWW_COLS * EPC];
+  const size_t C = (size_t)CPR * EPC;
+  const int cx = threadIdx.x % DWW_COLS, ly = threadIdx.x / DWW_COLS;
+  const int cc = blockIdx.y * DWW_COLS + cx;
+  float acc[9][EPC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[t][e] = 0.f;
+  if (cc < CPR) {
+    size_t p_end = ((size_t)blockIdx.x + 1) * per_strip;
+    if (p_end > opix) p_end = opix;
+    for (size_t p = (size_t)blockIdx.x * per_strip + ly; p < p_end; p += DWW_LANES) {
+      const int ox = (int)(p % OW); size_t t2 = p / OW;
+      const int oy = (int)(t2 % OH);
+      const size_t n = t2 / OH;
+      Chunk<T> g;
+      g.load(dout + p * C + (size_t)cc * EPC);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = oy * stride - 1 + r;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int ix = ox * stride - 1 + q;
+          if ((unsigned)ix >= (unsigned)W) continue;
+          Chunk<T> v;
+          v.load(in + ((n * H + iy) * W + ix) * C + (size_t)cc * EPC);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) acc[r * 3 + q][e] += g.v[e] * v.v[e];
+        }
+      }
+    }
+  }
+  // reduce the 8 pixel lanes, one tap at a time
+  for (int t = 0; t < 9; ++t) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[ly][cx * EPC + e] = acc[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < DWW_COLS * EPC; i += 256) {
+      const int ch = blockIdx.y * DWW_COLS * EPC + i;
+      if (ch < (int)C) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < DWW_LANES; ++l) s += red[l][i];
+        partial[((size_t)blockIdx.x * 9 + t) * C + ch] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ void dwconv3_wgrad_finalize_kernel(const float* __restrict__ partial, int nstrips, int C, int Cv, float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 9 * C: (tap, c)
+  if (i >= 9 * C) return;
+  const int t = i / C, c = i - t * C;
+  double s = 0.0;
+  for (int k = 0; k < nstrips; ++k) s += (double)partial[(size_t)k * 9 * C + i];
+  if (c < Cv) dw[(size_t)c * 9 + t] = (float)s;
+}
+template <typename T>
+int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
+                  int Cv, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_wgrad: C=%d stride=%d", C, stride);
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  const size_t opix = (size_t)N * OH * OW;
+  const int strips = dww_strips(opix);
+  const size_t per = (opix + strips - 1) / strips;
+  const int CPR = C / EPC;
+  hipLaunchKernelGGL(dwconv3_wgrad_kernel<T>, dim3(strips, ceil_div(CPR, DWW_COLS)), dim3(256), 0, st, dout, in, H, W, CPR, stride,
+                     OH, OW, opix, per, partial);
+  hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(9 * C, 256)), dim3(256), 0, st, partial, strips, C, Cv, dw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+#define INST_DW(T)                                                                                        \
+  template int dw_stage_weights<T>(const float*, int, int, T*, hipStream_t);                              \
+  template int dwconv3_fwd<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t);              \
+  template int dwconv3_dgrad<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t);            \
+  template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t);
+INST_DW(float)
+INST_DW(bf16_t)

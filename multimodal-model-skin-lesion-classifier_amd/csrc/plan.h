@@ -158,3 +158,4 @@ static inline double conv_bytes(const ConvShape& s, size_t es, int extra_in_shap
 PlanBase* make_resnet_plan(int arch, int N, int H, int W, int dtype, int* rc);
 PlanBase* make_densenet_plan(int N, int H, int W, int dtype, bool feature_map, int* rc);
 PlanBase* make_vgg_plan(int N, int H, int W, int dtype, int* rc);
+PlanBase* make_mobilenet_plan(int N, int H, int W, int dtype, int* rc);

@@ -398,19 +398,20 @@ size_t vgg_first_wgrad_slab_bytes(int N, int H, int W) {
 }
 template <typename T>
 int launch_vgg_first_conv_wgrad(int N, int H, int W, int Hp, int Wp, const T* dout, const T* img8, float* slab,
-                                float* dwv, hipStream_t st) {
+                                float* dwv, hipStream_t st, int stride) {
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
   WgradArgs a = {};
   a.dy = dout; a.in = img8; a.slab = slab;
   a.N = N; a.IH = Hp; a.IW = Wp; a.C = 32; a.Cpitch = 8;
-  a.OH = H; a.OW = W; a.Cout = 64; a.Ktot = 128;
-  a.Sy = 1; a.Sx = 1; a.ntaps = 4;
-  a.M = N * H * W;
+  a.OH = OH; a.OW = OW; a.Cout = 64; a.Ktot = 128;
+  a.Sy = stride; a.Sx = stride; a.ntaps = 4;
+  a.M = N * OH * OW;
   for (int r = 0; r < 4; ++r) { a.offy[r] = (int8_t)(r < 3 ? r : 0); a.offx[r] = 0; }
   return run_wgrad<T>(a, dwv, 128, 1, st);
 }
 
 #define INST(T)                                                                                   \
-  template int launch_vgg_first_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t); \
+  template int launch_vgg_first_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t, int); \
   template int launch_conv_wgrad<T>(const ConvShape&, const T*, const T*, float*, float*, hipStream_t, int, int); \
   template int launch_stem_conv_wgrad<T>(int, int, int, int, int, const T*, const T*, float*, float*, hipStream_t);
 INST(float)

@@ -453,6 +453,50 @@ class HipVGG16(nn.Module):
         return self.classifier(self.features(x).flatten(1))
 
 
+def _cna(cin, cout, k, stride, groups=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU6(inplace=True))
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, inp, oup, stride, t):
+        super().__init__()
+        hidden = inp * t
+        self.use_res_connect = stride == 1 and inp == oup
+        layers = []
+        if t != 1:
+            layers.append(_cna(inp, hidden, 1, 1))
+        layers += [_cna(hidden, hidden, 3, stride, groups=hidden), nn.Conv2d(hidden, oup, 1, bias=False), nn.BatchNorm2d(oup)]
+        self.conv = nn.Sequential(*layers)
+
+
+MOBILENET_V2_CFG = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+class HipMobileNetV2(_FlatBackbone):
+    """torchvision mobilenet_v2 module tree (features.N[.conv.K[.J]]) with `classifier = Identity`
+    (loadImageModelClassifier.py:96-100) -> 1280 features; plan executor csrc/mobilenet.hip."""
+
+    def __init__(self, name="mobilenet-v2", compute_dtype=None):
+        super().__init__()
+        if name != "mobilenet-v2":
+            raise ValueError(f"Backbone '{name}' não implementado.")
+        self.arch = name
+        feats, cin = [_cna(3, 32, 3, 2)], 32
+        for t, c, n, s in MOBILENET_V2_CFG:
+            for i in range(n):
+                feats.append(_InvertedResidual(cin, c, s if i == 0 else 1, t))
+                cin = c
+        feats.append(_cna(cin, 1280, 1, 1))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Identity()
+        self.num_features = 1280
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+        self._init_flat(compute_dtype)
+
+
 class HipCustomCNN(nn.Sequential):
     """loadImageModelClassifier.py:50-60: Conv(3,16,3,s2,p1)-ReLU-MaxPool2-GAP-Flatten-Linear(16,D)."""
 

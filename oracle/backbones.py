@@ -190,6 +190,57 @@ class OracleVGG16(nn.Module):
         return self.classifier(torch.flatten(self.avgpool(self.features(x)), 1))
 
 
+def _cna(cin, cout, k, stride, groups=1):
+    """torchvision Conv2dNormActivation(norm=BatchNorm2d, act=ReLU6): Sequential(0 conv, 1 bn, 2 relu6)."""
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU6(inplace=False))
+
+
+class _InvertedResidual(nn.Module):
+    def __init__(self, inp, oup, stride, t):
+        super().__init__()
+        hidden = inp * t
+        self.use_res_connect = stride == 1 and inp == oup
+        layers = []
+        if t != 1:
+            layers.append(_cna(inp, hidden, 1, 1))
+        layers += [_cna(hidden, hidden, 3, stride, groups=hidden), nn.Conv2d(hidden, oup, 1, bias=False), nn.BatchNorm2d(oup)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv(x) if self.use_res_connect else self.conv(x)
+
+
+MOBILENET_V2_CFG = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+class OracleMobileNetV2(nn.Module):
+    """torchvision mobilenet_v2 (width 1.0) with `classifier = Identity` (loadImageModelClassifier.py:96-100) -> 1280.
+    PARITY UNPINNED against torchvision (absent); module indices / state_dict keys follow it."""
+
+    def __init__(self):
+        super().__init__()
+        feats = [_cna(3, 32, 3, 2)]
+        cin = 32
+        for t, c, n, s in MOBILENET_V2_CFG:
+            for i in range(n):
+                feats.append(_InvertedResidual(cin, c, s if i == 0 else 1, t))
+                cin = c
+        feats.append(_cna(cin, 1280, 1, 1))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Identity()
+        self.num_features = 1280
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
+
+
 def custom_cnn(common_dim):
     """loadImageModelClassifier.py:50-60."""
     return nn.Sequential(
@@ -228,6 +279,9 @@ def build_image_encoder(name, common_dim, mode):
         dim = net.num_features
     elif name == "vgg16":
         net = OracleVGG16()
+        dim = net.num_features
+    elif name == "mobilenet-v2":
+        net = OracleMobileNetV2()
         dim = net.num_features
     elif name == "densenet169":
         net = OracleDenseNet169()

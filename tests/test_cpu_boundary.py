@@ -137,3 +137,15 @@ def test_vgg16_key_layout_and_plan():
     assert [k for k, p in m.named_parameters() if p.requires_grad] == ["classifier.3.weight", "classifier.3.bias"]
     plan = m.features._plan_for(2, 64, 64, None)          # layout check against the C plan happens inside
     assert plan.out_hw == (7, 7) and plan.feat_dim == 512
+
+
+def test_mobilenet_v2_key_layout_and_plan():
+    from models.loadImageModelClassifier import loadModels
+    from oracle.backbones import OracleMobileNetV2
+    m, dim = loadModels.loadModelImageEncoder("mobilenet-v2", 64, "last_layer_unfrozen_weights")
+    assert dim == 1280
+    ref = OracleMobileNetV2()
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert [k for k, p in m.named_parameters() if p.requires_grad] == ["features.18.1.weight", "features.18.1.bias"]
+    assert m._plan_for(2, 96, 96, None).feat_dim == 1280      # parameter / buffer layout is checked against the C plan inside
