@@ -1525,9 +1525,11 @@ int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int 
   return MMSKIN_OK;
 }
 
-// weight gradient: blockIdx.x = strip of output pixels, blockIdx.y = group of 32 chunk columns; 8 pixel lanes per block
-#define DWW_COLS 32
-#define DWW_LANES 8
+// weight gradient: blockIdx.x = strip of output pixels, blockIdx.y = group of 8 chunk columns; 32 pixel lanes per block
+// (channel counts here are 64..960: with 32 columns per block most lanes of the narrow early layers sat idle and one
+// launch took 1 ms)
+#define DWW_COLS 8
+#define DWW_LANES 32
 static inline int dww_strips(size_t opix) {
   size_t s = (opix + 2047) / 2048;
   if (s < 1) s = 1;
