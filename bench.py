@@ -58,6 +58,13 @@ WORKLOADS = {
                    attention_mecanism="crossattention"),
         "flop_per_image": 3 * 0.6e9,   # torchvision mobilenet_v2: 0.30 GMAC forward
     },
+    "efficientnetb0-crossattention": {
+        "metric": "images/sec fwd+bwd, EfficientNet-B0+crossattention bs=256",
+        "label": "EfficientNet-B0 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
+        "kw": dict(cnn_model_name="efficientnet-b0", text_model_name="one-hot-encoder", common_dim=512, vocab_size=20,
+                   attention_mecanism="crossattention"),
+        "flop_per_image": 3 * 0.78e9,   # torchvision efficientnet_b0: 0.39 GMAC forward
+    },
     "vgg16-crossattention": {
         "metric": "images/sec fwd+bwd, VGG-16+crossattention bs=256",
         "label": "VGG-16 + one-hot(20) + crossattention, 224x224, train step incl. Adam",

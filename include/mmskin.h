@@ -75,6 +75,9 @@ int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, c
  * last_conv_export returns that conv's output [N][C][OH][OW] (fp32) and last_conv_grad the gradient of the pooled
  * features w.r.t. it for a given d(score)/d(features) [N][C].  ResNet plans only. */
 int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value);
+/* per-step device pointers: key "sd_mask" (EfficientNet plans) = fp32 [n_residual_blocks][batch] keep/scale factors of
+ * torchvision's StochasticDepth(p, "row") for this training step (0 or 1/(1-p)); NULL disables stochastic depth */
+int mmskin_backbone_set_pointer(mmskin_backbone_t h, const char* key, const void* device_ptr);
 int mmskin_backbone_last_conv_shape(mmskin_backbone_t h, int* C, int* OH, int* OW);
 int mmskin_backbone_last_conv_export(mmskin_backbone_t h, const void* workspace, float* x_nchw, void* stream);
 int mmskin_backbone_last_conv_grad(mmskin_backbone_t h, const float* dfeatures, const void* workspace, float* dx_nchw,

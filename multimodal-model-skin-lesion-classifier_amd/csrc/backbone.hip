@@ -573,6 +573,8 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   else if (!strcmp(arch, "densenet169-features")) a = 1690;   // norm5 feature map, no ReLU / pool (MDNet)
   else if (!strcmp(arch, "vgg16-features")) a = 16;           // vgg16().features + avgpool -> [N][512][7][7]
   else if (!strcmp(arch, "mobilenet-v2")) a = 2;
+  else if (!strcmp(arch, "efficientnet-b0")) a = 100;
+  else if (!strcmp(arch, "efficientnet-b7")) a = 107;
   else { mmskin_set_error("backbone_create: Backbone '%s' has no HIP plan", arch); return MMSKIN_ERR_UNSUPPORTED; }
   ARG_CHECK(batch > 0 && height >= 32 && width >= 32, "backbone_create: bad shape %dx%dx%d", batch, height, width);
   ARG_CHECK(dtype == MMSKIN_F32 || dtype == MMSKIN_BF16, "backbone_create: dtype %d", dtype);
@@ -580,6 +582,7 @@ int mmskin_backbone_create(const char* arch, int batch, int height, int width, i
   PlanBase* p = (a == 169 || a == 1690) ? make_densenet_plan(batch, height, width, dtype, a == 1690, &rc)
                 : a == 16               ? make_vgg_plan(batch, height, width, dtype, &rc)
                 : a == 2                ? make_mobilenet_plan(batch, height, width, dtype, &rc)
+                : a >= 100              ? make_efficientnet_plan(a - 100, batch, height, width, dtype, &rc)
                                         : make_resnet_plan(a, batch, height, width, dtype, &rc);
   if (!p) return rc ? rc : MMSKIN_ERR_ARG;
   mmskin_backbone* h = new mmskin_backbone();
@@ -671,6 +674,12 @@ int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value) 
   if (!strcmp(key, "keep_raw_eval")) { h->plan->keep_raw_eval = value != 0; return MMSKIN_OK; }
   mmskin_set_error("backbone_set_option: unknown option '%s'", key);
   return MMSKIN_ERR_ARG;
+}
+int mmskin_backbone_set_pointer(mmskin_backbone_t h, const char* key, const void* device_ptr) {
+  ARG_CHECK(h && key, "backbone_set_pointer: null argument");
+  int rc = h->plan->set_pointer(key, device_ptr);
+  if (rc) mmskin_set_error("backbone_set_pointer: '%s' is not a pointer this plan takes", key);
+  return rc;
 }
 int mmskin_backbone_last_conv_shape(mmskin_backbone_t h, int* C, int* OH, int* OW) {
   ARG_CHECK(h && C && OH && OW, "backbone_last_conv_shape: null argument");

@@ -22,7 +22,7 @@ template <typename T>
 int bn_apply(const T* x, const T* res, const float* scale, const float* shift, const float* rscale,
              const float* rshift, T* y, size_t rows, int C, bool relu, hipStream_t st,
              uint8_t* mask_bits = nullptr,    // optional: one byte per 16-byte chunk, bit e = (y[e] > 0)
-             float relu_cap = 0.f);           // > 0: ReLU6-style clamp min(relu(.), cap)  (MobileNet)
+             float relu_cap = 0.f);           // > 0: ReLU6-style clamp min(relu(.), cap) (MobileNet); < 0 (with relu): SiLU
 // Column partial sums of an arbitrary NHWC tensor (used where no conv epilogue produced them).
 template <typename T>
 int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq, int* nrows_out,
@@ -30,7 +30,8 @@ int column_stats(const T* x, size_t rows, int C, float* stat_sum, float* stat_sq
 int column_stats_rows(size_t rows, int C);
 
 // ---- BatchNorm backward
-enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2, MASK_FROM_Y6 = 3 };   // Y6: 0 < y < 6 (ReLU6)
+enum { MASK_NONE = 0, MASK_FROM_X = 1, MASK_FROM_Y = 2, MASK_FROM_Y6 = 3,   // Y6: 0 < y < 6 (ReLU6)
+       MASK_SILU_X = 4 };   // dz = dy * silu'(x*scale + shift)
 int bn_bwd_partial_rows(size_t rows, int C);  // upper bound over dtypes (for sizing only)
 // partial[blk][0][C] = sum dz, partial[blk][1][C] = sum dz*x   with dz = dy * mask
 template <typename T>
@@ -154,18 +155,43 @@ int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, 
 
 // ---- depthwise 3x3 convolution (pad 1, stride 1 or 2) on NHWC T with C a multiple of the chunk width (MobileNet)
 // w_tc: staged weights [9][C] (tap-major) in T
+// ksize 3 or 5 (EfficientNet), padding ksize/2; staged weights [ksize*ksize][C]
 template <typename T>
-int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st);
+int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st, int ksize = 3);
 template <typename T>
-int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st);
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize = 3);
 template <typename T>
-int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st);
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize = 3);
 // dw[c][tap] (OIHW [C][1][3][3], first Cv channels written) = sum over output pixels of dout * shifted input;
 // partial: scratch of dwconv3_wgrad_partial_floats() floats
-size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride);
+size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride, int ksize = 3);
 template <typename T>
 int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
-                  int Cv, hipStream_t st);
+                  int Cv, hipStream_t st, int ksize = 3);
+
+// ---- squeeze-excitation and stochastic depth (EfficientNet MBConv)
+// y[n][hw][c] = x[n][hw][c] * gate[n][c]
+template <typename T>
+int se_scale_fwd(const T* x, const float* gate, int N, int HW, int C, T* y, hipStream_t st);
+// dgate[n][c] = sum_hw dy * x
+template <typename T>
+int se_dgate(const T* dy, const T* x, int N, int HW, int C, float* dgate, hipStream_t st);
+// dx = dy * gate + dpool[n][c] / HW   (dpool = gradient that reached the squeezed (average-pooled) input)
+template <typename T>
+int se_dx(const T* dy, const float* gate, const float* dpool, int N, int HW, int C, T* dx, hipStream_t st);
+// small fp32 vectors: mode 0 silu, 1 sigmoid (forward);  backward: dz = dout * f'(z)
+int ew_act_fwd(const float* z, float* out, int64_t n, int mode, hipStream_t st);
+int ew_act_bwd(const float* dout, const float* z, float* dz, int64_t n, int mode, hipStream_t st);
+// fp32 matrix padding helpers: dst[r][c] = (r < rows && c < cols) ? src[r*cols + c] : 0 for a rows_p x cols_p dst
+int pad_matrix(const float* src, int rows, int cols, int rows_p, int cols_p, float* dst, hipStream_t st);
+// stochastic depth (row mode): y = branch * mask[n] + res;  out = dy * mask[n]
+template <typename T>
+int sd_residual_add(const T* branch, const T* res, const float* mask, int N, size_t per_sample, T* y, hipStream_t st);
+// out = a + b  (n elements, multiple of the chunk width)
+template <typename T>
+int ew_add(const T* a, const T* b, T* out, size_t n, hipStream_t st);
+template <typename T>
+int sd_row_scale(const T* dy, const float* mask, int N, size_t per_sample, T* out, hipStream_t st);
 
 // ---- layout converters used by the op-level C ABI (tests / small tensors)
 template <typename T>

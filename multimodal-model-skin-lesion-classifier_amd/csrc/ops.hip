@@ -246,8 +246,10 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
       float t = v.v[e] * scale[c0 + e] + shift[c0 + e];
       if (RES == 1) t += r.v[e];
       if (RES == 2) t += r.v[e] * rscale[c0 + e] + rshift[c0 + e];
-      if (RELU) t = fmaxf(t, 0.f);
-      if (RELU && relu_cap > 0.f) t = fminf(t, relu_cap);
+      if (RELU) {
+        if (relu_cap < 0.f) t = t / (1.f + __expf(-t));             // SiLU
+        else { t = fmaxf(t, 0.f); if (relu_cap > 0.f) t = fminf(t, relu_cap); }
+      }
       v.v[e] = t;
       bits |= (from_f32<T>(t) != 0 && t > 0.f ? 1u : 0u) << e;   // bit = (stored y > 0)
     }
@@ -338,6 +340,13 @@ __device__ __forceinline__ void masked_dy(Chunk<T>& dz, const Chunk<T>& xv, cons
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
       if (!(yv.v[e] > 0.f && yv.v[e] < 6.f)) dz.v[e] = 0.f;
+  } else if (MODE == MASK_SILU_X) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float t = xv.v[e] * scale[c0 + e] + shift[c0 + e];
+      const float sg = 1.f / (1.f + __expf(-t));
+      dz.v[e] *= sg * (1.f + t * (1.f - sg));
+    }
   }
 }
 
@@ -382,6 +391,7 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
   if (mask_mode == MASK_FROM_X) LAUNCH(MASK_FROM_X);
   else if (mask_mode == MASK_FROM_Y) LAUNCH(MASK_FROM_Y);
   else if (mask_mode == MASK_FROM_Y6) LAUNCH(MASK_FROM_Y6);
+  else if (mask_mode == MASK_SILU_X) LAUNCH(MASK_SILU_X);
   else LAUNCH(MASK_NONE);
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
@@ -470,6 +480,7 @@ int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, co
   if (mask_mode == MASK_FROM_X) { if (dz_out) LAUNCH(MASK_FROM_X, true); else LAUNCH(MASK_FROM_X, false); }
   else if (mask_mode == MASK_FROM_Y) { if (dz_out) LAUNCH(MASK_FROM_Y, true); else LAUNCH(MASK_FROM_Y, false); }
   else if (mask_mode == MASK_FROM_Y6) { if (dz_out) LAUNCH(MASK_FROM_Y6, true); else LAUNCH(MASK_FROM_Y6, false); }
+  else if (mask_mode == MASK_SILU_X) { if (dz_out) LAUNCH(MASK_SILU_X, true); else LAUNCH(MASK_SILU_X, false); }
   else { if (dz_out) LAUNCH(MASK_NONE, true); else LAUNCH(MASK_NONE, false); }
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
@@ -1411,28 +1422,30 @@ int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, 
 template int gap_relu_bn_grad<float>(const float*, const float*, const float*, int, int, int, float*, hipStream_t);
 template int gap_relu_bn_grad<bf16_t>(const float*, const bf16_t*, const float*, int, int, int, float*, hipStream_t);
 
-// ------------------------------------------------------------------ depthwise 3x3 (MobileNet)
+// ------------------------------------------------------------------ depthwise k x k (k = 3 MobileNet / 3, 5 EfficientNet)
 template <typename T>
-__global__ void dw_stage_weights_kernel(const float* __restrict__ w, int C, int Cp, T* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 9 * Cp: (tap, c)
-  if (i < 9 * Cp) {
+__global__ void dw_stage_weights_kernel(const float* __restrict__ w, int C, int Cp, int KK, T* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // over KK * Cp: (tap, c)
+  if (i < KK * Cp) {
     int t = i / Cp, c = i - t * Cp;
-    out[i] = from_f32<T>(c < C ? w[(size_t)c * 9 + t] : 0.f);
+    out[i] = from_f32<T>(c < C ? w[(size_t)c * KK + t] : 0.f);
   }
 }
 template <typename T>
-int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st) {
-  hipLaunchKernelGGL(dw_stage_weights_kernel<T>, dim3(ceil_div(9 * Cp, 256)), dim3(256), 0, st, w_oihw, C, Cp, w_tc);
+int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st, int ksize) {
+  const int KK = ksize * ksize;
+  hipLaunchKernelGGL(dw_stage_weights_kernel<T>, dim3(ceil_div(KK * Cp, 256)), dim3(256), 0, st, w_oihw, C, Cp, KK, w_tc);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, int H, int W,
-                                                              int CPR, int stride, int OH, int OW, T* __restrict__ out,
+                                                              int CPR, int stride, int K, int OH, int OW, T* __restrict__ out,
                                                               size_t nchunks) {
   constexpr int EPC = DT<T>::EPC;
   const size_t C = (size_t)CPR * EPC;
+  const int pad = K / 2;
   for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
     const int cc = (int)(i % CPR);
     size_t t = i / CPR;
@@ -1442,17 +1455,15 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restri
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int iy = oy * stride - 1 + r;
+    for (int r = 0; r < K; ++r) {
+      const int iy = oy * stride - pad + r;
       if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int ix = ox * stride - 1 + q;
+      for (int q = 0; q < K; ++q) {
+        const int ix = ox * stride - pad + q;
         if ((unsigned)ix >= (unsigned)W) continue;
         Chunk<T> v, wv;
         v.load(in + ((n * H + iy) * W + ix) * C + (size_t)cc * EPC);
-        wv.load(w + (size_t)(r * 3 + q) * C + (size_t)cc * EPC);
+        wv.load(w + (size_t)(r * K + q) * C + (size_t)cc * EPC);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] += v.v[e] * wv.v[e];
       }
@@ -1464,22 +1475,24 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restri
   }
 }
 template <typename T>
-int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st) {
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize) {
   constexpr int EPC = DT<T>::EPC;
-  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_fwd: C=%d stride=%d", C, stride);
-  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_fwd: C=%d stride=%d k=%d", C, stride, ksize);
+  const int pad = ksize / 2;
+  const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
   const size_t nch = (size_t)N * OH * OW * (C / EPC);
-  hipLaunchKernelGGL(dwconv3_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, in, w_tc, H, W, C / EPC, stride, OH, OW, out, nch);
+  hipLaunchKernelGGL(dwconv3_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, in, w_tc, H, W, C / EPC, stride, ksize, OH, OW, out, nch);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __restrict__ dout, const T* __restrict__ w, int H, int W,
-                                                                int CPR, int stride, int OH, int OW, T* __restrict__ din,
+                                                                int CPR, int stride, int K, int OH, int OW, T* __restrict__ din,
                                                                 size_t nchunks) {
   constexpr int EPC = DT<T>::EPC;
   const size_t C = (size_t)CPR * EPC;
+  const int pad = K / 2;
   for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
     const int cc = (int)(i % CPR);
     size_t t = i / CPR;
@@ -1489,21 +1502,19 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __rest
     float acc[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ty = iy + 1 - r;
+    for (int r = 0; r < K; ++r) {
+      const int ty = iy + pad - r;
       if (ty < 0 || ty % stride != 0) continue;
       const int oy = ty / stride;
       if (oy >= OH) continue;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int tx = ix + 1 - q;
+      for (int q = 0; q < K; ++q) {
+        const int tx = ix + pad - q;
         if (tx < 0 || tx % stride != 0) continue;
         const int ox = tx / stride;
         if (ox >= OW) continue;
         Chunk<T> g, wv;
         g.load(dout + ((n * OH + oy) * OW + ox) * C + (size_t)cc * EPC);
-        wv.load(w + (size_t)(r * 3 + q) * C + (size_t)cc * EPC);
+        wv.load(w + (size_t)(r * K + q) * C + (size_t)cc * EPC);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] += g.v[e] * wv.v[e];
       }
@@ -1515,19 +1526,20 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __rest
   }
 }
 template <typename T>
-int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st) {
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize) {
   constexpr int EPC = DT<T>::EPC;
-  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_dgrad: C=%d stride=%d", C, stride);
-  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_dgrad: C=%d stride=%d k=%d", C, stride, ksize);
+  const int pad = ksize / 2;
+  const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
   const size_t nch = (size_t)N * H * W * (C / EPC);
-  hipLaunchKernelGGL(dwconv3_dgrad_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dout, w_tc, H, W, C / EPC, stride, OH, OW, din, nch);
+  hipLaunchKernelGGL(dwconv3_dgrad_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dout, w_tc, H, W, C / EPC, stride, ksize, OH, OW, din, nch);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
-// weight gradient: blockIdx.x = strip of output pixels, blockIdx.y = group of 8 chunk columns; 32 pixel lanes per block
-// (channel counts here are 64..960: with 32 columns per block most lanes of the narrow early layers sat idle and one
-// launch took 1 ms)
+// weight gradient: blockIdx.x = strip of output pixels, blockIdx.y = group of 8 chunk columns, blockIdx.z = kernel row;
+// 32 pixel lanes per block (channel counts here are 64..1152 wide: with 32 columns per block most lanes of the narrow
+// early layers sat idle and one launch took 1 ms).  One kernel row (<= 5 taps) per block keeps the accumulators in registers.
 #define DWW_COLS 8
 #define DWW_LANES 32
 static inline int dww_strips(size_t opix) {
@@ -1536,22 +1548,24 @@ static inline int dww_strips(size_t opix) {
   if (s > 4096) s = 4096;
   return (int)s;
 }
-size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride) {
-  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
-  return (size_t)dww_strips((size_t)N * OH * OW) * 9 * C;
+size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride, int ksize) {
+  const int pad = ksize / 2;
+  const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
+  return (size_t)dww_strips((size_t)N * OH * OW) * ksize * ksize * C;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const T* __restrict__ dout, const T* __restrict__ in, int H, int W,
-                                                           int CPR, int stride, int OH, int OW, size_t opix, size_t per_strip,
-                                                           float* __restrict__ partial) {
+                                                           int CPR, int stride, int K, int OH, int OW, size_t opix,
+                                                           size_t per_strip, float* __restrict__ partial) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ float red[DWW_LANES][DWW_COLS * EPC];
   const size_t C = (size_t)CPR * EPC;
+  const int pad = K / 2, r = blockIdx.z, KK = K * K;
   const int cx = threadIdx.x % DWW_COLS, ly = threadIdx.x / DWW_COLS;
   const int cc = blockIdx.y * DWW_COLS + cx;
-  float acc[9][EPC];
+  float acc[5][EPC];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 5; ++t)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[t][e] = 0.f;
   if (cc < CPR) {
@@ -1561,70 +1575,244 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const T* __restrict_
       const int ox = (int)(p % OW); size_t t2 = p / OW;
       const int oy = (int)(t2 % OH);
       const size_t n = t2 / OH;
+      const int iy = oy * stride - pad + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
       Chunk<T> g;
       g.load(dout + p * C + (size_t)cc * EPC);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int iy = oy * stride - 1 + r;
-        if ((unsigned)iy >= (unsigned)H) continue;
+      for (int q = 0; q < 5; ++q) {
+        if (q >= K) break;
+        const int ix = ox * stride - pad + q;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        Chunk<T> v;
+        v.load(in + ((n * H + iy) * W + ix) * C + (size_t)cc * EPC);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int ix = ox * stride - 1 + q;
-          if ((unsigned)ix >= (unsigned)W) continue;
-          Chunk<T> v;
-          v.load(in + ((n * H + iy) * W + ix) * C + (size_t)cc * EPC);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) acc[r * 3 + q][e] += g.v[e] * v.v[e];
-        }
+        for (int e = 0; e < EPC; ++e) acc[q][e] += g.v[e] * v.v[e];
       }
     }
   }
-  // reduce the 8 pixel lanes, one tap at a time
-  for (int t = 0; t < 9; ++t) {
+  for (int q = 0; q < K; ++q) {   // reduce the pixel lanes, one tap at a time
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) red[ly][cx * EPC + e] = acc[t][e];
+    for (int e = 0; e < EPC; ++e) red[ly][cx * EPC + e] = acc[q][e];
     __syncthreads();
     for (int i = threadIdx.x; i < DWW_COLS * EPC; i += 256) {
       const int ch = blockIdx.y * DWW_COLS * EPC + i;
       if (ch < (int)C) {
-        float s = 0.f;
+        float s2 = 0.f;
 #pragma unroll
-        for (int l = 0; l < DWW_LANES; ++l) s += red[l][i];
-        partial[((size_t)blockIdx.x * 9 + t) * C + ch] = s;
+        for (int l = 0; l < DWW_LANES; ++l) s2 += red[l][i];
+        partial[((size_t)blockIdx.x * KK + r * K + q) * C + ch] = s2;
       }
     }
     __syncthreads();
   }
 }
-__global__ void dwconv3_wgrad_finalize_kernel(const float* __restrict__ partial, int nstrips, int C, int Cv, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over 9 * C: (tap, c)
-  if (i >= 9 * C) return;
+__global__ void dwconv3_wgrad_finalize_kernel(const float* __restrict__ partial, int nstrips, int C, int Cv, int KK,
+                                              float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over KK * C: (tap, c)
+  if (i >= KK * C) return;
   const int t = i / C, c = i - t * C;
   double s = 0.0;
-  for (int k = 0; k < nstrips; ++k) s += (double)partial[(size_t)k * 9 * C + i];
-  if (c < Cv) dw[(size_t)c * 9 + t] = (float)s;
+  for (int k = 0; k < nstrips; ++k) s += (double)partial[(size_t)k * KK * C + i];
+  if (c < Cv) dw[(size_t)c * KK + t] = (float)s;
 }
 template <typename T>
 int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
-                  int Cv, hipStream_t st) {
+                  int Cv, hipStream_t st, int ksize) {
   constexpr int EPC = DT<T>::EPC;
-  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2), "dwconv3_wgrad: C=%d stride=%d", C, stride);
-  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_wgrad: C=%d stride=%d k=%d", C, stride, ksize);
+  const int pad = ksize / 2;
+  const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
   const size_t opix = (size_t)N * OH * OW;
   const int strips = dww_strips(opix);
   const size_t per = (opix + strips - 1) / strips;
-  const int CPR = C / EPC;
-  hipLaunchKernelGGL(dwconv3_wgrad_kernel<T>, dim3(strips, ceil_div(CPR, DWW_COLS)), dim3(256), 0, st, dout, in, H, W, CPR, stride,
-                     OH, OW, opix, per, partial);
-  hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(9 * C, 256)), dim3(256), 0, st, partial, strips, C, Cv, dw);
+  const int CPR = C / EPC, KK = ksize * ksize;
+  hipLaunchKernelGGL(dwconv3_wgrad_kernel<T>, dim3(strips, ceil_div(CPR, DWW_COLS), ksize), dim3(256), 0, st, dout, in, H, W, CPR,
+                     stride, ksize, OH, OW, opix, per, partial);
+  hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(KK * C, 256)), dim3(256), 0, st, partial, strips, C, Cv, KK, dw);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ------------------------------------------------------------------ squeeze-excitation, stochastic depth (EfficientNet)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void se_scale_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gate, int HW,
+                                                               int CPR, T* __restrict__ y, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    const size_t n = i / CPR / HW;
+    const float* g = gate + (n * CPR + cc) * EPC;
+    Chunk<T> v;
+    v.load(x + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.v[e] *= g[e];
+    v.store(y + i * EPC);
+  }
+}
+template <typename T>
+int se_scale_fwd(const T* x, const float* gate, int N, int HW, int C, T* y, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "se_scale_fwd: C=%d", C);
+  const size_t nch = (size_t)N * HW * (C / EPC);
+  hipLaunchKernelGGL(se_scale_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, x, gate, HW, C / EPC, y, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void se_dgate_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int HW,
+                                                           int CPR, float* __restrict__ dgate) {
+  constexpr int EPC = DT<T>::EPC;
+  const int total = N * CPR;
+  for (int i = blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * EW_BLOCK) {
+    const int n = i / CPR, cc = i - n * CPR;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      Chunk<T> a, b;
+      const size_t off = (((size_t)n * HW + p) * CPR + cc) * EPC;
+      a.load(dy + off); b.load(x + off);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += a.v[e] * b.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dgate[(size_t)i * EPC + e] = acc[e];
+  }
+}
+template <typename T>
+int se_dgate(const T* dy, const T* x, int N, int HW, int C, float* dgate, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "se_dgate: C=%d", C);
+  hipLaunchKernelGGL(se_dgate_kernel<T>, dim3(ew_grid((size_t)N * (C / EPC))), dim3(EW_BLOCK), 0, st, dy, x, N, HW, C / EPC, dgate);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void se_dx_kernel(const T* __restrict__ dy, const float* __restrict__ gate,
+                                                        const float* __restrict__ dpool, int HW, int CPR, T* __restrict__ dx,
+                                                        size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const float inv = 1.f / (float)HW;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cc = (int)(i % CPR);
+    const size_t n = i / CPR / HW;
+    const size_t go = (n * CPR + cc) * EPC;
+    Chunk<T> v;
+    v.load(dy + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.v[e] = v.v[e] * gate[go + e] + dpool[go + e] * inv;
+    v.store(dx + i * EPC);
+  }
+}
+template <typename T>
+int se_dx(const T* dy, const float* gate, const float* dpool, int N, int HW, int C, T* dx, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "se_dx: C=%d", C);
+  const size_t nch = (size_t)N * HW * (C / EPC);
+  hipLaunchKernelGGL(se_dx_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dy, gate, dpool, HW, C / EPC, dx, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+__global__ void ew_act_fwd_kernel(const float* __restrict__ z, float* __restrict__ out, int64_t n, int mode) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = z[i], sg = 1.f / (1.f + expf(-t));
+    out[i] = mode == 0 ? t * sg : sg;
+  }
+}
+__global__ void ew_act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ z, float* __restrict__ dz, int64_t n,
+                                  int mode) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = z[i], sg = 1.f / (1.f + expf(-t));
+    dz[i] = dout[i] * (mode == 0 ? sg * (1.f + t * (1.f - sg)) : sg * (1.f - sg));
+  }
+}
+int ew_act_fwd(const float* z, float* out, int64_t n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(ew_act_fwd_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, st, z, out, n, mode);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int ew_act_bwd(const float* dout, const float* z, float* dz, int64_t n, int mode, hipStream_t st) {
+  hipLaunchKernelGGL(ew_act_bwd_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, st, dout, z, dz, n, mode);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+__global__ void pad_matrix_kernel(const float* __restrict__ src, int rows, int cols, int rows_p, int cols_p, float* __restrict__ dst) {
+  const int64_t total = (int64_t)rows_p * cols_p;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_p), c = (int)(i - (int64_t)r * cols_p);
+    dst[i] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+}
+int pad_matrix(const float* src, int rows, int cols, int rows_p, int cols_p, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(pad_matrix_kernel, dim3(ew_grid((size_t)rows_p * cols_p)), dim3(256), 0, st, src, rows, cols, rows_p, cols_p, dst);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T, bool ADD>
+__global__ __launch_bounds__(EW_BLOCK) void sd_kernel(const T* __restrict__ a, const T* __restrict__ res, const float* __restrict__ mask,
+                                                     size_t chunks_per_sample, T* __restrict__ y, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const float m = mask[i / chunks_per_sample];
+    Chunk<T> v, r;
+    v.load(a + i * EPC);
+    if (ADD) r.load(res + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v.v[e] = v.v[e] * m + (ADD ? r.v[e] : 0.f);
+    v.store(y + i * EPC);
+  }
+}
+template <typename T>
+int sd_residual_add(const T* branch, const T* res, const float* mask, int N, size_t per_sample, T* y, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(per_sample % EPC == 0, "sd_residual_add: per-sample size");
+  const size_t nch = (size_t)N * (per_sample / EPC);
+  hipLaunchKernelGGL((sd_kernel<T, true>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, branch, res, mask, per_sample / EPC, y, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+int sd_row_scale(const T* dy, const float* mask, int N, size_t per_sample, T* out, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(per_sample % EPC == 0, "sd_row_scale: per-sample size");
+  const size_t nch = (size_t)N * (per_sample / EPC);
+  hipLaunchKernelGGL((sd_kernel<T, false>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dy, (const T*)nullptr, mask, per_sample / EPC, out, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void ew_add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                         size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    Chunk<T> u, v;
+    u.load(a + i * EPC); v.load(b + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) u.v[e] += v.v[e];
+    u.store(out + i * EPC);
+  }
+}
+template <typename T>
+int ew_add(const T* a, const T* b, T* out, size_t n, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(n % EPC == 0, "ew_add: size");
+  hipLaunchKernelGGL(ew_add_kernel<T>, dim3(ew_grid(n / EPC)), dim3(EW_BLOCK), 0, st, a, b, out, n / EPC);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
 #define INST_DW(T)                                                                                        \
-  template int dw_stage_weights<T>(const float*, int, int, T*, hipStream_t);                              \
-  template int dwconv3_fwd<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t);              \
-  template int dwconv3_dgrad<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t);            \
-  template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t);
+  template int dw_stage_weights<T>(const float*, int, int, T*, hipStream_t, int);                         \
+  template int dwconv3_fwd<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int);         \
+  template int dwconv3_dgrad<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int);       \
+  template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t, int); \
+  template int se_scale_fwd<T>(const T*, const float*, int, int, int, T*, hipStream_t);                   \
+  template int se_dgate<T>(const T*, const T*, int, int, int, float*, hipStream_t);                       \
+  template int se_dx<T>(const T*, const float*, const float*, int, int, int, T*, hipStream_t);            \
+  template int sd_residual_add<T>(const T*, const T*, const float*, int, size_t, T*, hipStream_t);        \
+  template int ew_add<T>(const T*, const T*, T*, size_t, hipStream_t);                                    \
+  template int sd_row_scale<T>(const T*, const float*, int, size_t, T*, hipStream_t);
 INST_DW(float)
 INST_DW(bf16_t)

@@ -101,6 +101,8 @@ struct PlanBase {
   virtual int last_conv_shape(int*, int*, int*) const { return MMSKIN_ERR_UNSUPPORTED; }
   virtual int last_conv_export(const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }
   virtual int last_conv_grad(const float*, const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }
+  // per-step device pointers handed in by the host (e.g. "sd_mask": stochastic-depth keep/scale factors)
+  virtual int set_pointer(const char*, const void*) { return MMSKIN_ERR_UNSUPPORTED; }
   // per-unit introspection (tests / diagnostics); plans without it report zero units
   virtual int num_units() const { return 0; }
   virtual int unit_info(int, std::string*, int64_t*) const { return MMSKIN_ERR_UNSUPPORTED; }
@@ -159,3 +161,4 @@ PlanBase* make_resnet_plan(int arch, int N, int H, int W, int dtype, int* rc);
 PlanBase* make_densenet_plan(int N, int H, int W, int dtype, bool feature_map, int* rc);
 PlanBase* make_vgg_plan(int N, int H, int W, int dtype, int* rc);
 PlanBase* make_mobilenet_plan(int N, int H, int W, int dtype, int* rc);
+PlanBase* make_efficientnet_plan(int variant, int N, int H, int W, int dtype, int* rc);

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "mmskin_backbone_feature_dim": (_i, [_P]),
     "mmskin_backbone_feature_hw": (_i, [_P, _P, _P]),
     "mmskin_backbone_set_option": (_i, [_P, ctypes.c_char_p, _i]),
+    "mmskin_backbone_set_pointer": (_i, [_P, ctypes.c_char_p, _P]),
     "mmskin_backbone_last_conv_shape": (_i, [_P, _P, _P, _P]),
     "mmskin_backbone_last_conv_export": (_i, [_P, _P, _P, _P]),
     "mmskin_backbone_last_conv_grad": (_i, [_P, _P, _P, _P, _P]),

@@ -497,6 +497,112 @@ class HipMobileNetV2(_FlatBackbone):
         self._init_flat(compute_dtype)
 
 
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+EFFICIENTNET_CFG = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
+                    (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+EFFICIENTNET_SCALE = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b7": (2.0, 3.1)}
+
+
+class _SqueezeExcitation(nn.Module):
+    def __init__(self, channels, squeeze):
+        super().__init__()
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc1 = nn.Conv2d(channels, squeeze, 1)
+        self.fc2 = nn.Conv2d(squeeze, channels, 1)
+        self.activation = nn.SiLU(inplace=True)
+        self.scale_activation = nn.Sigmoid()
+
+
+class StochasticDepth(nn.Module):
+    """Parameter-less holder of torchvision's StochasticDepth(p, "row"); the plan applies the per-sample mask."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+        self.mode = "row"
+
+
+class _MBConv(nn.Module):
+    def __init__(self, cin, cout, expand, k, stride, sd_prob, norm):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        hidden = _make_divisible(cin * expand)
+
+        def cna(ci, co, kk, st, groups, act):
+            layers = [nn.Conv2d(ci, co, kk, st, (kk - 1) // 2, groups=groups, bias=False), norm(co)]
+            if act:
+                layers.append(nn.SiLU(inplace=True))
+            return nn.Sequential(*layers)
+        layers = []
+        if hidden != cin:
+            layers.append(cna(cin, hidden, 1, 1, 1, True))
+        layers.append(cna(hidden, hidden, k, stride, hidden, True))
+        layers.append(_SqueezeExcitation(hidden, max(1, cin // 4)))
+        layers.append(cna(hidden, cout, 1, 1, 1, False))
+        self.block = nn.Sequential(*layers)
+        self.stochastic_depth = StochasticDepth(sd_prob)
+
+
+class HipEfficientNet(_FlatBackbone):
+    """torchvision efficientnet_b0 / efficientnet_b7 module tree with `classifier = Identity`
+    (loadImageModelClassifier.py:102-112) -> 1280 / 2560 features; plan executor csrc/effnet.hip."""
+
+    def __init__(self, name, compute_dtype=None):
+        super().__init__()
+        if name not in EFFICIENTNET_SCALE:
+            raise ValueError(f"Backbone '{name}' não implementado.")
+        import math
+        from functools import partial
+        self.arch = name
+        width, depth = EFFICIENTNET_SCALE[name]
+        adj = lambda c: _make_divisible(c * width)
+        norm = partial(nn.BatchNorm2d, eps=0.001, momentum=0.01) if name == "efficientnet-b7" else nn.BatchNorm2d
+        stages = [[(adj(i) if li == 0 else adj(o), adj(o), e, k, s if li == 0 else 1) for li in range(int(math.ceil(n * depth)))]
+                  for e, k, s, i, o, n in EFFICIENTNET_CFG]
+        total = sum(len(st) for st in stages)
+        feats = [nn.Sequential(nn.Conv2d(3, adj(32), 3, 2, 1, bias=False), norm(adj(32)), nn.SiLU(inplace=True))]
+        bid = 0
+        for st in stages:
+            blocks = []
+            for cin, cout, e, k, s in st:
+                blocks.append(_MBConv(cin, cout, e, k, s, 0.2 * bid / total, norm))
+                bid += 1
+            feats.append(nn.Sequential(*blocks))
+        last = stages[-1][-1][1]
+        feats.append(nn.Sequential(nn.Conv2d(last, 4 * last, 1, bias=False), norm(4 * last), nn.SiLU(inplace=True)))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Identity()
+        self.num_features = 4 * last
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        self._sd_mask = None
+        self._init_flat(compute_dtype)
+
+    def forward(self, image):
+        if self.training:   # this step's stochastic-depth masks (torchvision: bernoulli(1-p) / (1-p) per sample, per block)
+            u8 = image.dtype == torch.uint8
+            n, h, w = (image.shape[0], image.shape[1], image.shape[2]) if u8 else (image.shape[0], image.shape[2], image.shape[3])
+            plan = self._plan_for(n, h, w, image.device)
+            probs = [m.stochastic_depth.p for m in self.modules() if isinstance(m, _MBConv) and m.use_res_connect]
+            if any(p > 0 for p in probs):
+                pr = torch.tensor(probs, device=image.device, dtype=torch.float32)[:, None]
+                self._sd_mask = ((torch.rand(len(probs), n, device=image.device) >= pr).float() / (1.0 - pr)).contiguous()
+                call("mmskin_backbone_set_pointer", plan.handle, b"sd_mask", ptr(self._sd_mask))
+            else:
+                self._sd_mask = None
+                call("mmskin_backbone_set_pointer", plan.handle, b"sd_mask", None)
+        return super().forward(image)
+
+
 class HipCustomCNN(nn.Sequential):
     """loadImageModelClassifier.py:50-60: Conv(3,16,3,s2,p1)-ReLU-MaxPool2-GAP-Flatten-Linear(16,D)."""
 

@@ -2,7 +2,7 @@
 
 Same static-method API, argument meaning, return values and error strings as the reference's
 ``loadModels``.  Image backbones with a gfx950 plan: ``custom-cnn``, ``resnet-18``, ``resnet-50``,
-``densenet169``, ``vgg16``, ``mobilenet-v2``.
+``densenet169``, ``vgg16``, ``mobilenet-v2``, ``efficientnet-b0/b7``.
 Weights are randomly initialised (torchvision layout and init); pretrained checkpoints are loaded by
 the caller with ``load_state_dict`` -- there is no network access from this package.
 """
@@ -16,11 +16,11 @@ for _p in (_PKG, os.path.dirname(os.path.abspath(__file__))):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-from mmskin.backbone import RESNET_DEPTHS, HipCustomCNN, HipDenseNet, HipMobileNetV2, HipResNet, HipVGG16  # noqa: E402
+from mmskin.backbone import RESNET_DEPTHS, HipCustomCNN, HipDenseNet, HipEfficientNet, HipMobileNetV2, HipResNet, HipVGG16  # noqa: E402
 from tab_transformer import TabTransformer  # noqa: E402
 
 # Backbones the reference accepts (loadImageModelClassifier.py:65-118) that have no HIP plan yet.
-_KNOWN_WITHOUT_PLAN = ("efficientnet-b0", "efficientnet-b7")
+_KNOWN_WITHOUT_PLAN = ()
 
 
 class loadModels:
@@ -61,6 +61,10 @@ class loadModels:
         elif cnn_model_name == "mobilenet-v2":
             model = HipMobileNetV2(cnn_model_name)
             cnn_dim_output = model.num_features
+            loadModels.set_backbone_train_mode(model, backbone_train_mode, last_n_layers=1)
+        elif cnn_model_name in ("efficientnet-b0", "efficientnet-b7"):
+            model = HipEfficientNet(cnn_model_name)
+            cnn_dim_output = model.num_features     # 1280 / 2560 (reference :104,110)
             loadModels.set_backbone_train_mode(model, backbone_train_mode, last_n_layers=1)
         elif cnn_model_name == "densenet169":
             model = HipDenseNet(cnn_model_name)

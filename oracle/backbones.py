@@ -241,6 +241,123 @@ class OracleMobileNetV2(nn.Module):
         return self.classifier(torch.flatten(F.adaptive_avg_pool2d(x, 1), 1))
 
 
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+class _CNA(nn.Sequential):
+    """torchvision Conv2dNormActivation: Sequential(0 conv, 1 norm[, 2 activation])."""
+
+    def __init__(self, cin, cout, k, stride, groups, norm, act):
+        layers = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), norm(cout)]
+        if act:
+            layers.append(nn.SiLU(inplace=False))
+        super().__init__(*layers)
+
+
+class _SqueezeExcitation(nn.Module):
+    def __init__(self, channels, squeeze):
+        super().__init__()
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc1 = nn.Conv2d(channels, squeeze, 1)
+        self.fc2 = nn.Conv2d(squeeze, channels, 1)
+        self.activation = nn.SiLU()
+        self.scale_activation = nn.Sigmoid()
+
+    def forward(self, x):
+        s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
+        return s * x
+
+
+class StochasticDepth(nn.Module):
+    """torchvision.ops.StochasticDepth(p, "row")."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = 1.0 - self.p
+        noise = torch.empty([x.shape[0]] + [1] * (x.dim() - 1), dtype=x.dtype, device=x.device).bernoulli_(keep)
+        if keep > 0:
+            noise.div_(keep)
+        return x * noise
+
+
+class _MBConv(nn.Module):
+    def __init__(self, cin, cout, expand, k, stride, sd_prob, norm):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        hidden = _make_divisible(cin * expand)
+        layers = []
+        if hidden != cin:
+            layers.append(_CNA(cin, hidden, 1, 1, 1, norm, True))
+        layers.append(_CNA(hidden, hidden, k, stride, hidden, norm, True))
+        layers.append(_SqueezeExcitation(hidden, max(1, cin // 4)))
+        layers.append(_CNA(hidden, cout, 1, 1, 1, norm, False))
+        self.block = nn.Sequential(*layers)
+        self.stochastic_depth = StochasticDepth(sd_prob)
+
+    def forward(self, x):
+        r = self.block(x)
+        return self.stochastic_depth(r) + x if self.use_res_connect else r
+
+
+EFFICIENTNET_CFG = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
+                    (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+EFFICIENTNET_SCALE = {"efficientnet-b0": (1.0, 1.0), "efficientnet-b7": (2.0, 3.1)}
+
+
+def efficientnet_blocks(name):
+    """-> list of stages, each a list of (cin, cout, expand, k, stride, sd_prob); torchvision _efficientnet_conf."""
+    import math
+    width, depth = EFFICIENTNET_SCALE[name]
+    adj = lambda c: _make_divisible(c * width)
+    stages = [[(adj(i) if li == 0 else adj(o), adj(o), e, k, s if li == 0 else 1) for li in range(int(math.ceil(n * depth)))]
+              for e, k, s, i, o, n in EFFICIENTNET_CFG]
+    total = sum(len(st) for st in stages)
+    out, bid = [], 0
+    for st in stages:
+        cur = []
+        for cin, cout, e, k, s in st:
+            cur.append((cin, cout, e, k, s, 0.2 * bid / total))
+            bid += 1
+        out.append(cur)
+    return out, adj(32)
+
+
+class OracleEfficientNet(nn.Module):
+    """torchvision efficientnet_b0 / efficientnet_b7 with `classifier = Identity` (loadImageModelClassifier.py:102-112)
+    -> 1280 / 2560 features.  PARITY UNPINNED against torchvision (absent); module tree / state_dict keys follow it."""
+
+    def __init__(self, name):
+        super().__init__()
+        from functools import partial
+        norm = partial(nn.BatchNorm2d, eps=0.001, momentum=0.01) if name == "efficientnet-b7" else nn.BatchNorm2d
+        stages, stem = efficientnet_blocks(name)
+        feats = [_CNA(3, stem, 3, 2, 1, norm, True)]
+        for st in stages:
+            feats.append(nn.Sequential(*[_MBConv(cin, cout, e, k, s, p, norm) for cin, cout, e, k, s, p in st]))
+        last = stages[-1][-1][1]
+        feats.append(_CNA(last, 4 * last, 1, 1, 1, norm, True))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Identity()
+        self.num_features = 4 * last
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        return self.classifier(torch.flatten(F.adaptive_avg_pool2d(self.features(x), 1), 1))
+
+
 def custom_cnn(common_dim):
     """loadImageModelClassifier.py:50-60."""
     return nn.Sequential(
@@ -282,6 +399,9 @@ def build_image_encoder(name, common_dim, mode):
         dim = net.num_features
     elif name == "mobilenet-v2":
         net = OracleMobileNetV2()
+        dim = net.num_features
+    elif name in EFFICIENTNET_SCALE:
+        net = OracleEfficientNet(name)
         dim = net.num_features
     elif name == "densenet169":
         net = OracleDenseNet169()

@@ -23,6 +23,8 @@ def disable_dropout(model):
             m.p = 0.0
         if isinstance(m, nn.MultiheadAttention):
             m.dropout = 0.0                      # attention-probability dropout (a float, not a module)
+        if type(m).__name__ == "StochasticDepth":
+            m.p = 0.0
         for attr in ("dropout_p", "drop_p"):
             if hasattr(m, attr):
                 setattr(m, attr, 0.0)

@@ -149,3 +149,16 @@ def test_mobilenet_v2_key_layout_and_plan():
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
     assert [k for k, p in m.named_parameters() if p.requires_grad] == ["features.18.1.weight", "features.18.1.bias"]
     assert m._plan_for(2, 96, 96, None).feat_dim == 1280      # parameter / buffer layout is checked against the C plan inside
+
+
+def test_efficientnet_key_layout_and_plan():
+    from models.loadImageModelClassifier import loadModels
+    from oracle.backbones import OracleEfficientNet
+    for name, dim in (("efficientnet-b0", 1280), ("efficientnet-b7", 2560)):
+        m, d = loadModels.loadModelImageEncoder(name, 64, "frozen_weights")
+        assert d == dim
+        ref = OracleEfficientNet(name)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+        assert not any(p.requires_grad for p in m.parameters())
+        assert m._plan_for(2, 64, 64, None).feat_dim == dim      # parameter / buffer layout checked against the C plan inside

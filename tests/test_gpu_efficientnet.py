@@ -1,0 +1,112 @@
+"""EfficientNet-B0 / B7 image encoders (loadImageModelClassifier.py:102-112) on the HIP plan executor vs the CPU
+oracle (torchvision layout, parity unpinned against torchvision itself).  Covers SiLU, squeeze-excitation, 3x3 / 5x5
+depthwise convolutions (stride 1 and 2) and row-mode stochastic depth."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import SMALL, disable_dropout
+from gpu_util import DEV, rel_err
+from oracle.backbones import OracleEfficientNet
+from oracle.detinit import det_init_, det_inputs, det_tensor
+from oracle.model import OracleMultimodalModel
+
+pytestmark = pytest.mark.gpu
+
+
+def _l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _pair(name, dtype):
+    from mmskin.backbone import HipEfficientNet
+    cpu = det_init_(OracleEfficientNet(name))
+    hip = HipEfficientNet(name, compute_dtype=dtype)
+    hip.load_state_dict(cpu.state_dict(), strict=True)
+    return cpu, hip.to(DEV)
+
+
+@pytest.mark.parametrize("name,hw", [("efficientnet-b0", 64), ("efficientnet-b0", 96), ("efficientnet-b7", 64)])
+def test_efficientnet_eval_features_fp32(name, hw):
+    cpu, hip = _pair(name, "fp32")
+    cpu.eval(); hip.eval()
+    x = det_tensor("eff.img%d" % hw, (2, 3, hw, hw))
+    with torch.no_grad():
+        a, b = cpu(x), hip(x.to(DEV)).cpu()
+    assert b.shape == a.shape == (2, cpu.num_features)
+    assert rel_err(b, a) < 2e-4, rel_err(b, a)
+
+
+@pytest.mark.parametrize("name", ["efficientnet-b0", "efficientnet-b7"])
+def test_efficientnet_train_step_vs_oracle_fp32(name):
+    """Stochastic depth off (p = 0, as dropout in every parity test): features, BN running statistics and every
+    gradient against the fp64 oracle, at most 3x the CPU fp32 oracle's own distance."""
+    cpu, hip = _pair(name, "fp32")
+    truth = det_init_(OracleEfficientNet(name)).double()
+    N = 4
+    x = det_tensor("eff.img", (N, 3, 64, 64))
+    w = det_tensor("eff.w", (N, cpu.num_features))
+    outs, grads = {}, {}
+    for nm, m, xi, wi in (("cpu", cpu, x, w), ("truth", truth, x.double(), w.double()), ("hip", hip, x.to(DEV), w.to(DEV))):
+        m.train(); disable_dropout(m)
+        f = m(xi)
+        (f * wi).sum().backward()
+        outs[nm] = f.detach().cpu().double()
+        grads[nm] = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
+    assert set(grads["hip"]) == set(grads["truth"])
+    assert all(torch.isfinite(g).all() for g in grads["hip"].values())
+    keys = list(grads["truth"])
+    f_hip, f_cpu = _l2(outs["hip"], outs["truth"]), _l2(outs["cpu"], outs["truth"])
+    cpu_l2 = sorted(_l2(grads["cpu"][k], grads["truth"][k]) for k in keys)
+    hip_l2 = sorted(_l2(grads["hip"][k], grads["truth"][k]) for k in keys)
+    print(name, "feat", f_hip, f_cpu, "grad median", hip_l2[len(keys) // 2], cpu_l2[len(keys) // 2], "p90", hip_l2[int(len(keys) * 0.9)], cpu_l2[int(len(keys) * 0.9)])
+    assert f_hip < 3 * f_cpu + 1e-4, (f_hip, f_cpu)
+    assert hip_l2[len(keys) // 2] <= 3 * cpu_l2[len(keys) // 2] + 1e-4
+    assert hip_l2[int(len(keys) * 0.9)] <= 3 * cpu_l2[int(len(keys) * 0.9)] + 1e-3
+    bn_c = [m for m in cpu.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    bn_h = [m for m in hip.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert rel_err(bn_h[-1].running_var, bn_c[-1].running_var) < 1e-3 and rel_err(bn_h[10].running_mean, bn_c[10].running_mean) < 1e-3
+
+
+def test_efficientnet_stochastic_depth_and_bf16():
+    """Train mode with torchvision's stochastic-depth probabilities: the per-sample masks are 0 or 1/(1-p); a sample whose
+    every residual branch is kept must equal the p = 0 forward.  Also one bf16 train step for finiteness."""
+    from mmskin.backbone import HipEfficientNet
+    torch.manual_seed(0)
+    hip = HipEfficientNet("efficientnet-b0", compute_dtype="fp32").to(DEV).train()
+    x = torch.randn(16, 3, 64, 64, device=DEV)
+    f_sd = hip(x)
+    mask = hip._sd_mask.clone()                      # [9 residual blocks, 16]
+    assert mask.shape == (9, 16)
+    probs = torch.tensor([m.stochastic_depth.p for m in hip.modules() if hasattr(m, "stochastic_depth") and m.use_res_connect], device=DEV)
+    assert torch.all((mask == 0) | ((mask - 1 / (1 - probs[:, None])).abs() < 1e-6))
+    f_sd.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in hip.parameters())
+    os.environ["MMSKIN_BACKBONE_DTYPE"] = "bf16"
+    hb = HipEfficientNet("efficientnet-b0").to(DEV).train()
+    hb(x).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in hb.parameters())
+
+
+def test_efficientnet_in_multimodal_model():
+    from models import multimodalIntraInterModal as M
+    os.environ["MMSKIN_BACKBONE_DTYPE"] = "fp32"
+    kw = dict(SMALL, cnn_model_name="efficientnet-b0", attention_mecanism="weighted", unfreeze_weights="unfrozen_weights")
+    cpu = det_init_(OracleMultimodalModel(**dict(kw, device="cpu")))
+    hip = M.MultimodalModel(**dict(kw, device=DEV))
+    hip.load_state_dict(cpu.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    img, meta, lab = det_inputs(5, 64, 20, 6)
+    res = {}
+    for name, m, dev in (("cpu", cpu, "cpu"), ("hip", hip, DEV)):
+        m.train(); disable_dropout(m)
+        out = m(img.to(dev), meta.to(dev))
+        F.cross_entropy(out, lab.to(dev)).backward()
+        res[name] = (out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
+    assert (res["cpu"][0] - res["hip"][0]).abs().max() < 1e-3
+    assert set(res["cpu"][1]) == set(res["hip"][1])
+    head = [k for k in res["cpu"][1] if not k.startswith("image_encoder")]
+    assert max(_l2(res["hip"][1][k], res["cpu"][1][k]) for k in head) < 5e-3
