@@ -300,7 +300,7 @@ int eff_forward(EffPlan& p, const void* image, const float* norm6, const float* 
       float* a1 = reinterpret_cast<float*>(ws + se.a1_off);
       float* z2 = reinterpret_cast<float*>(ws + se.z2_off);
       float* g = reinterpret_cast<float*>(ws + se.g_off);
-      if ((rc = avgpool_fwd<T>(y, p.N, u.OH * u.OW, Cp, s, st))) return rc;
+      if ((rc = gap_reduce<T>(y, nullptr, p.N, u.OH * u.OW, Cp, 1.f / (float)(u.OH * u.OW), s, st))) return rc;
       if ((rc = mmskin_linear_forward(s, reinterpret_cast<const float*>(ws + se.w1p_off), params + se.b1_off, z1, p.N, Cp, se.Csq, 0, st))) return rc;
       if ((rc = ew_act_fwd(z1, a1, (int64_t)p.N * se.Csq, 0, st))) return rc;
       if ((rc = mmskin_linear_forward(a1, reinterpret_cast<const float*>(ws + se.w2p_off), reinterpret_cast<const float*>(ws + se.b2p_off),
@@ -356,7 +356,7 @@ int eff_backward(EffPlan& p, const float* dfeat, const float* params, unsigned c
       float* dw1p = t; t += (size_t)se.Csq * Cp;
       float* dw2p = t; t += (size_t)Cp * se.Csq;
       float* db2p = t; t += Cp;
-      if ((rc = se_dgate<T>(B[cur], y, p.N, HW, Cp, dgate, st))) return rc;
+      if ((rc = gap_reduce<T>(B[cur], y, p.N, HW, Cp, 1.f, dgate, st))) return rc;
       if ((rc = ew_act_bwd(dgate, z2, dz2, (int64_t)p.N * Cp, 1, st))) return rc;
       if ((rc = mmskin_linear_backward(dz2, a1, reinterpret_cast<const float*>(ws + se.w2p_off), nullptr, nullptr, da1, dw2p, db2p,
                                        p.N, se.Csq, Cp, st))) return rc;

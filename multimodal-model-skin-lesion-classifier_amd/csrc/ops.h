@@ -173,6 +173,10 @@ int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int st
 // y[n][hw][c] = x[n][hw][c] * gate[n][c]
 template <typename T>
 int se_scale_fwd(const T* x, const float* gate, int N, int HW, int C, T* y, hipStream_t st);
+// out[n][c] = scale * sum_hw a[n][hw][c] * (b ? b[n][hw][c] : 1): block-parallel over the pixels (the per-thread loops of
+// avgpool_fwd / se_dgate are sized for 7x7 maps; squeeze-excitation pools 112x112 ones)
+template <typename T>
+int gap_reduce(const T* a, const T* b, int N, int HW, int C, float scale, float* out, hipStream_t st);
 // dgate[n][c] = sum_hw dy * x
 template <typename T>
 int se_dgate(const T* dy, const T* x, int N, int HW, int C, float* dgate, hipStream_t st);

@@ -1659,6 +1659,56 @@ int se_scale_fwd(const T* x, const float* gate, int N, int HW, int C, T* y, hipS
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
+template <typename T, bool PROD>
+__global__ __launch_bounds__(256) void gap_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b, int HW, int CPR,
+                                                        float scale, float* __restrict__ out) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[32][8 * EPC];
+  const int cx = threadIdx.x & 7, ly = threadIdx.x >> 3;   // 8 chunk columns x 32 pixel lanes
+  const int cc = blockIdx.x * 8 + cx;
+  const size_t n = blockIdx.y;
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  if (cc < CPR)
+    for (int p = ly; p < HW; p += 32) {
+      const size_t off = ((n * HW + p) * CPR + cc) * EPC;
+      Chunk<T> u;
+      u.load(a + off);
+      if (PROD) {
+        Chunk<T> v;
+        v.load(b + off);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += u.v[e] * v.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] += u.v[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) red[ly][cx * EPC + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 8 * EPC) {
+    const int ch = blockIdx.x * 8 * EPC + threadIdx.x;
+    if (ch < CPR * EPC) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int l = 0; l < 32; ++l) s2 += red[l][threadIdx.x];
+      out[n * CPR * EPC + ch] = s2 * scale;
+    }
+  }
+}
+template <typename T>
+int gap_reduce(const T* a, const T* b, int N, int HW, int C, float scale, float* out, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0, "gap_reduce: C=%d", C);
+  const int CPR = C / EPC;
+  if (b) hipLaunchKernelGGL((gap_reduce_kernel<T, true>), dim3(ceil_div(CPR, 8), N), dim3(256), 0, st, a, b, HW, CPR, scale, out);
+  else hipLaunchKernelGGL((gap_reduce_kernel<T, false>), dim3(ceil_div(CPR, 8), N), dim3(256), 0, st, a, b, HW, CPR, scale, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void se_dgate_kernel(const T* __restrict__ dy, const T* __restrict__ x, int N, int HW,
                                                            int CPR, float* __restrict__ dgate) {
@@ -1810,6 +1860,7 @@ int ew_add(const T* a, const T* b, T* out, size_t n, hipStream_t st) {
   template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t, int); \
   template int se_scale_fwd<T>(const T*, const float*, int, int, int, T*, hipStream_t);                   \
   template int se_dgate<T>(const T*, const T*, int, int, int, float*, hipStream_t);                       \
+  template int gap_reduce<T>(const T*, const T*, int, int, int, float, float*, hipStream_t);              \
   template int se_dx<T>(const T*, const float*, const float*, int, int, int, T*, hipStream_t);            \
   template int sd_residual_add<T>(const T*, const T*, const float*, int, size_t, T*, hipStream_t);        \
   template int ew_add<T>(const T*, const T*, T*, size_t, hipStream_t);                                    \
