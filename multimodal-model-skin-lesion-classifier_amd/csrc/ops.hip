@@ -225,7 +225,7 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
   return MMSKIN_OK;
 }
 
-template <typename T, bool RELU, int RES>  // RES: 0 none, 1 plain residual, 2 residual*rscale + rshift
+template <typename T, int RELU, int RES>  // RELU: 0 none, 1 relu / capped relu, 2 SiLU; RES: 0 none, 1 plain residual, 2 residual*rscale + rshift
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -246,10 +246,10 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
       float t = v.v[e] * scale[c0 + e] + shift[c0 + e];
       if (RES == 1) t += r.v[e];
       if (RES == 2) t += r.v[e] * rscale[c0 + e] + rshift[c0 + e];
-      if (RELU) {
-        if (relu_cap < 0.f) t = t / (1.f + __expf(-t));             // SiLU
-        else { t = fmaxf(t, 0.f); if (relu_cap > 0.f) t = fminf(t, relu_cap); }
-      }
+      // SiLU is its own instantiation: as a run-time branch its exp + divide were if-converted into the ReLU path
+      // and made the (HBM-bound) pass VALU-bound -- 3x slower BatchNorm-apply on every backbone
+      if (RELU == 2) t = t / (1.f + __expf(-t));
+      else if (RELU == 1) { t = fmaxf(t, 0.f); if (relu_cap > 0.f) t = fminf(t, relu_cap); }
       v.v[e] = t;
       bits |= (from_f32<T>(t) != 0 && t > 0.f ? 1u : 0u) << e;   // bit = (stored y > 0)
     }
@@ -268,8 +268,9 @@ int bn_apply(const T* x, const T* res, const float* scale, const float* shift, c
   int grid = ew_grid(nch);
   int mode = res ? (rscale ? 2 : 1) : 0;
 #define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC, relu_cap)
-  if (relu) { if (mode == 2) LAUNCH(true, 2); else if (mode == 1) LAUNCH(true, 1); else LAUNCH(true, 0); }
-  else { if (mode == 2) LAUNCH(false, 2); else if (mode == 1) LAUNCH(false, 1); else LAUNCH(false, 0); }
+  if (relu && relu_cap < 0.f) { if (mode == 2) LAUNCH(2, 2); else if (mode == 1) LAUNCH(2, 1); else LAUNCH(2, 0); }
+  else if (relu) { if (mode == 2) LAUNCH(1, 2); else if (mode == 1) LAUNCH(1, 1); else LAUNCH(1, 0); }
+  else { if (mode == 2) LAUNCH(0, 2); else if (mode == 1) LAUNCH(0, 1); else LAUNCH(0, 0); }
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -779,7 +780,7 @@ template <typename T>
 int stage_weights(const StageDesc* table_dev, int nlayers, int max_elems, const float* params, T* wfwd,
                   T* wdgrad, bool need_dgrad, hipStream_t st, const float* fold_buffers, float eps) {
   int gx = ceil_div(max_elems / DT<T>::EPC, EW_BLOCK * 2);
-  if (gx > 64) gx = 64;
+  if (gx > 2048) gx = 2048;   // short workgroups (one or two chunks per thread): 0.30 -> see DESIGN.md
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(stage_weights_kernel<T>, dim3(gx, nlayers, need_dgrad ? 2 : 1), dim3(EW_BLOCK), 0, st, table_dev,
                      params, wfwd, wdgrad, need_dgrad ? 1 : 0, fold_buffers, eps);
