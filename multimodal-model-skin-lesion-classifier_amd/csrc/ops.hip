@@ -153,6 +153,11 @@ static inline int reduce_groups(int nrows) {
   return g > 64 ? 64 : (g < 1 ? 1 : g);
 }
 
+// partial-row counts up to this are reduced by the finalize kernel itself (one launch instead of two)
+#ifndef BN_SINGLE_STAGE_ROWS
+#define BN_SINGLE_STAGE_ROWS 64
+#endif
+
 // ------------------------------------------------------------------ BN forward
 template <typename IN>
 __global__ void bn_finalize_kernel(const IN* __restrict__ ssum, const IN* __restrict__ ssq, int nrows,
@@ -192,7 +197,7 @@ int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, d
                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                 float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
                 double* scratch, hipStream_t st) {
-  if (scratch && nrows > 64) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(stat_sum, stat_sq, nrows, C, G, scratch, st);
     if (rc) return rc;
@@ -434,7 +439,7 @@ int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const 
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                     float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad) {
   if (n_grad < 0) n_grad = C;
-  if (scratch && nrows > 64) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;
@@ -1025,7 +1030,7 @@ __global__ void bn_table_finalize_kernel(const IN* __restrict__ ssum, const IN* 
 int bn_table_finalize(const float* stat_sum, const float* stat_sq, int nrows, int stride, int C, double count,
                       float* mean, float* var, double* scratch, hipStream_t st) {
   const bool interleaved = stat_sq == stat_sum + C && stride == 2 * C;   // slice_stats slab
-  if (scratch && nrows > 64) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc;
     if (interleaved) {
@@ -1380,7 +1385,7 @@ __global__ void bias_grad_finalize_kernel(const IN* __restrict__ part, int nrows
   if (ry == 0 && c < C) db[c] = (float)((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]));
 }
 int bias_grad_finalize(const float* partial, int nrows, int stride, int C, float* db, double* scratch, hipStream_t st) {
-  if (scratch && nrows > 64) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(partial, nullptr, nrows, stride, G, scratch, st);
     if (rc) return rc;
