@@ -500,8 +500,21 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   Unit& u0 = p.units[0];
   T* dyfull = S[2];
   T* dx0 = S[3];
-  PROF(K_STEM_MISC, 0.0, 0.0, maxpool_bwd<T>(g, ws + p.off_idx, p.N, p.OH0, p.OW0, 64, dyfull, st));
-  if ((rc = bn_backward(u0, dyfull, nullptr, MASK_FROM_X, dx0, nullptr))) return rc;
+  {   // max-pool + ReLU + BatchNorm backward without materialising the full-resolution pooled gradient
+    float* c0 = reinterpret_cast<float*>(ws + u0.coef_off);
+    const T* x0 = reinterpret_cast<const T*>(ws + u0.x_off);
+    float* cB = cA + 64; float* cC = cA + 128;
+    int nr = 0;
+    (void)dyfull;
+    p.prof.begin(K_BN_BWD, st);
+    rc = stem_pool_bn_bwd_reduce<T>(g, ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
+    if (!rc) rc = bn_bwd_finalize(partial, nr, 64, (double)u0.rows(), params + u0.g_off, c0 + 128, c0 + 192, grads + u0.g_off,
+                                  grads + u0.b_off, cA, cB, cC, reinterpret_cast<double*>(ws + p.off_red), st);
+    if (!rc) rc = stem_pool_bn_bwd_apply<T>(g, ws + p.off_idx, x0, c0, c0 + 64, cA, cB, cC, p.N, p.OH0, p.OW0, 64, dx0, st);
+    p.prof.end(st);
+    if (p.prof.on) p.prof.bytes[K_BN_BWD] += 3.5 * u0.rows() * 64 * sizeof(T);
+    if (rc) return rc;
+  }
   float* dwv = reinterpret_cast<float*>(ws + p.off_dwv);
   PROF(K_WGRAD, conv_flops(u0.s), 0.0,
        launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),

@@ -540,12 +540,11 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
     float* cB = cA + 64; float* cC = cA + 128;
     int nr = 0;
     PROF(K_STEM_MISC, 0.0, 0.0, slice_pack<T>(reinterpret_cast<const T*>(ws + b.dcat_off), b.Ctot, 64, 64, b.rows, nullptr, nullptr, sB, st));
-    PROF(K_STEM_MISC, 0.0, 0.0, maxpool_bwd<T>(sB, ws + p.off_idx, p.N, p.OH0, p.OW0, 64, sZ, st));
-    p.prof.begin(K_BN_BWD, st);
-    rc = bn_bwd_reduce<T>(sZ, x0, nullptr, c0, c0 + 64, MASK_FROM_X, rows0, 64, partial, &nr, st);
+    p.prof.begin(K_BN_BWD, st);   // max-pool + ReLU + BatchNorm backward straight from the pooled gradient
+    rc = stem_pool_bn_bwd_reduce<T>(sB, ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
     if (!rc) rc = bn_bwd_finalize(partial, nr, 64, (double)rows0, params + p.n0.g_off, c0 + 128, c0 + 192, grads + p.n0.g_off,
                                   grads + p.n0.b_off, cA, cB, cC, red, st);
-    if (!rc) rc = bn_bwd_apply<T>(sZ, x0, nullptr, c0, c0 + 64, MASK_FROM_X, cA, cB, cC, sX, nullptr, rows0, 64, st);
+    if (!rc) rc = stem_pool_bn_bwd_apply<T>(sB, ws + p.off_idx, x0, c0, c0 + 64, cA, cB, cC, p.N, p.OH0, p.OW0, 64, sX, st);
     p.prof.end(st);
     if (rc) return rc;
     float* dwv = reinterpret_cast<float*>(ws + p.off_dwv);

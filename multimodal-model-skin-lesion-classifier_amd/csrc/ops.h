@@ -65,6 +65,16 @@ int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N,
 template <typename T>
 int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, T* dy_full, hipStream_t st);
 
+// Stem backward without the full-resolution un-pooled gradient: dz = maxpool_bwd(dpool)[n][h][w][c] * (x*scale+shift > 0) is
+// recomputed from the pooled gradient + argmax bytes inside the BatchNorm-backward reduce and apply passes
+// (saves one 411 MB write and two reads of it at batch 256).
+template <typename T>
+int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N,
+                            int H, int W, int C, float* partial, int* nrows_out, hipStream_t st);
+template <typename T>
+int stem_pool_bn_bwd_apply(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift,
+                           const float* cA, const float* cB, const float* cC, int N, int H, int W, int C, T* dx, hipStream_t st);
+
 // ---- global average pool
 template <typename T>
 int avgpool_fwd(const T* x, int N, int HW, int C, float* feat, hipStream_t st);

@@ -677,6 +677,119 @@ int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, 
   return MMSKIN_OK;
 }
 
+// gradient of the 3x3/2 max-pool input at (n, h, w), chunk cj: sum of the pooled gradients whose argmax is this pixel
+template <typename T>
+__device__ __forceinline__ void pool_grad_chunk(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, size_t n, int h, int w,
+                                                int cj, int C, int PH, int PW, float (&acc)[DT<T>::EPC]) {
+  constexpr int EPC = DT<T>::EPC;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  for (int ph = h / 2; ph <= (h + 1) / 2; ++ph) {
+    if (ph >= PH) continue;
+    int r = h - (2 * ph - 1);
+    for (int pw = w / 2; pw <= (w + 1) / 2; ++pw) {
+      if (pw >= PW) continue;
+      int s = w - (2 * pw - 1);
+      const int tap = r * 3 + s;
+      size_t po = ((n * PH + ph) * PW + pw) * C + cj * EPC;
+      Chunk<T> g;
+      g.load(dpool + po);
+      uint32_t iw[2] = {0u, 0u};
+      if constexpr (EPC == 8) {
+        uint2 q = *reinterpret_cast<const uint2*>(idx + po);
+        iw[0] = q.x; iw[1] = q.y;
+      } else {
+        iw[0] = *reinterpret_cast<const uint32_t*>(idx + po);
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        if ((int)((iw[e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += g.v[e];
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                     const T* __restrict__ x, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, int H, int W, int C, int PH,
+                                                                     int PW, size_t rows, ColGeom g, float* partial) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[2 * 256 * EPC];
+  const int cx = threadIdx.x % g.CW, ry = threadIdx.x / g.CW;
+  const int col = blockIdx.y * g.CW + cx;
+  float acc[2][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  if (ry < g.RL && col < g.CPR) {
+    size_t r_end = (size_t)(blockIdx.x + 1) * g.RB;
+    if (r_end > rows) r_end = rows;
+    const int c0 = col * EPC;
+    for (size_t r = (size_t)blockIdx.x * g.RB + ry; r < r_end; r += g.RL) {
+      const int w = (int)(r % W); size_t t = r / W;
+      const int h = (int)(t % H);
+      const size_t n = t / H;
+      float dz[EPC];
+      pool_grad_chunk<T>(dpool, idx, n, h, w, col, C, PH, PW, dz);
+      Chunk<T> xv;
+      xv.load(x + (r * g.CPR + col) * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float d = (xv.v[e] * scale[c0 + e] + shift[c0 + e] > 0.f) ? dz[e] : 0.f;
+        acc[0][e] += d; acc[1][e] += d * xv.v[e];
+      }
+    }
+  }
+  block_col_reduce<EPC, 2>(acc, cx, ry, g.CW, g.RL, col, g.CPR, C, partial, red);
+}
+template <typename T>
+int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N,
+                            int H, int W, int C, float* partial, int* nrows_out, hipStream_t st) {
+  ARG_CHECK(C % DT<T>::EPC == 0, "stem_pool_bn_bwd_reduce: C=%d", C);
+  const size_t rows = (size_t)N * H * W;
+  const int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
+  ColGeom g = col_geom(rows, C, DT<T>::EPC);
+  hipLaunchKernelGGL(stem_pool_bn_bwd_reduce_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, st, dpool, idx, x, scale, shift, H, W, C, PH,
+                     PW, rows, g, partial);
+  HIP_CHECK_RET(hipGetLastError());
+  *nrows_out = g.gx;
+  return MMSKIN_OK;
+}
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void stem_pool_bn_bwd_apply_kernel(
+    const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
+    int H, int W, int C, int PH, int PW, T* __restrict__ dx, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  const int CPR = C / EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const int cj = (int)(i % CPR), c0 = cj * EPC;
+    size_t t = i / CPR;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const size_t n = t / H;
+    float dz[EPC];
+    pool_grad_chunk<T>(dpool, idx, n, h, w, cj, C, PH, PW, dz);
+    Chunk<T> xv;
+    xv.load(x + i * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float d = (xv.v[e] * scale[c0 + e] + shift[c0 + e] > 0.f) ? dz[e] : 0.f;
+      xv.v[e] = cA[c0 + e] * d + cB[c0 + e] * xv.v[e] + cC[c0 + e];
+    }
+    xv.store(dx + i * EPC);
+  }
+}
+template <typename T>
+int stem_pool_bn_bwd_apply(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift,
+                           const float* cA, const float* cB, const float* cC, int N, int H, int W, int C, T* dx, hipStream_t st) {
+  ARG_CHECK(C % DT<T>::EPC == 0, "stem_pool_bn_bwd_apply: C=%d", C);
+  const int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
+  const size_t nch = (size_t)N * H * W * (C / DT<T>::EPC);
+  hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dpool, idx, x, scale, shift, cA, cB,
+                     cC, H, W, C, PH, PW, dx, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 // ------------------------------------------------------------------ global average pool
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void avgpool_fwd_kernel(const T* __restrict__ x, int N, int HW, int C,
@@ -873,6 +986,8 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
   template int stem_pack_u8<T>(const uint8_t*, int, int, int, int, int, const float*, T*, hipStream_t);        \
   template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \
   template int maxpool_bwd<T>(const T*, const uint8_t*, int, int, int, int, T*, hipStream_t);                   \
+  template int stem_pool_bn_bwd_reduce<T>(const T*, const uint8_t*, const T*, const float*, const float*, int, int, int, int, float*, int*, hipStream_t); \
+  template int stem_pool_bn_bwd_apply<T>(const T*, const uint8_t*, const T*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, T*, hipStream_t); \
   template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \
   template int avgpool_bwd<T>(const float*, int, int, int, T*, hipStream_t);                                    \
   template int stage_weights<T>(const StageDesc*, int, int, const float*, T*, T*, bool, hipStream_t, const float*, float); \
