@@ -170,6 +170,19 @@ int mmskin_mdnet_fuse_forward(const float* feat, const float* z, const float* t1
 int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const float* z, const float* t1, const float* t2,
                                float* dfeat /* may be NULL */, float* dz, float* dt1, float* dt2, int64_t NC, int HW,
                                void* stream);
+/* Encoder-layer pieces for the HuggingFace text encoders (loadImageModelClassifier.py:170-181, bert-base-uncased):
+ * strided batched GEMM  C[b](m,n) = sum_k A[b](m,k) * B[b](n,k)  with A[b](m,k) = a[b*sab + m*sam + k*sak] (likewise B),
+ * C[b] = c + b*scb with row pitch ldc -- QK^T, PV and their gradients;
+ * row softmax with scale and an additive per-batch key mask (mask_add [batch][L], may be NULL); exact (erf) GELU. */
+int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t sam, int64_t sak, int64_t sab,
+               int64_t sbn, int64_t sbk, int64_t sbb, int64_t ldc, int64_t scb, void* stream);
+int mmskin_softmax_forward(const float* x, const float* mask_add, float* y, int64_t rows, int L, int64_t rows_per_batch,
+                           float scale, void* stream);
+int mmskin_softmax_backward(const float* dy, const float* y, float* dx, int64_t rows, int L, float scale, void* stream);
+/* y = a + b, b broadcast over the leading dimension when nb < n (residual sums, position embeddings) */
+int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream);
+int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream);
+int mmskin_gelu_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 /* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
                              void* stream);

@@ -5,6 +5,7 @@
 // row reductions (LayerNorm, softmax) are wavefront-shuffle reductions, one 64-lane wave per row.
 #include "../../include/mmskin.h"
 #include "common.h"
+#include "conv.h"
 
 #define ST(s) ((hipStream_t)(s))
 
@@ -47,9 +48,13 @@ template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        float* __restrict__ c, const float* __restrict__ bias, int M,
                                                        int N, int K, int64_t sam, int64_t sak, int64_t sbn,
-                                                       int64_t sbk, int64_t ldc, int relu, int kchunk) {
+                                                       int64_t sbk, int64_t ldc, int relu, int kchunk, int64_t sab,
+                                                       int64_t sbb, int64_t scb) {
   __shared__ float As[LG_BK * LG_PM];
   __shared__ float Bs[LG_BK * LG_PM];
+  if (kchunk < 0) {   // batched: blockIdx.z = batch index (no split-K)
+    a += (int64_t)blockIdx.z * sab; b += (int64_t)blockIdx.z * sbb; c += (int64_t)blockIdx.z * scb;
+  }
   // split-K (kchunk > 0): slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and writes its own M x ldc
   // partial matrix; the caller sums the slices.  Used by the weight-gradient GEMMs whose K is batch*tokens.
   if (kchunk > 0) {
@@ -110,10 +115,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 }
 
 static int gemm_f32(const float* a, const float* b, float* c, const float* bias, int M, int N, int K, int64_t sam,
-                    int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int relu, hipStream_t st) {
+                    int64_t sak, int64_t sbn, int64_t sbk, int64_t ldc, int relu, hipStream_t st, int batch = 1,
+                    int64_t sab = 0, int64_t sbb = 0, int64_t scb = 0) {
   if (M <= 0 || N <= 0) return MMSKIN_OK;
   dim3 grid(ceil_div(N, LG_T), ceil_div(M, LG_T));
   const bool akc = sak == 1, bkc = sbk == 1;
+  if (batch > 1) {
+    grid.z = batch;
+#define LAUNCHB(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, c, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu, -1, sab, sbb, scb)
+    if (akc && bkc) LAUNCHB(true, true);
+    else if (akc) LAUNCHB(true, false);
+    else if (bkc) LAUNCHB(false, true);
+    else LAUNCHB(false, false);
+#undef LAUNCHB
+    HIP_CHECK_RET(hipGetLastError());
+    return MMSKIN_OK;
+  }
   // few output tiles but a long contraction (dW = dY^T X over batch*tokens rows): split K over blockIdx.z
   int S = 1, kchunk = 0;
   float* out = c;
@@ -129,7 +146,7 @@ static int gemm_f32(const float* a, const float* b, float* c, const float* bias,
       grid.z = S;
     }
   }
-#define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, out, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu, S > 1 ? kchunk : 0)
+#define LAUNCH(X, Y) hipLaunchKernelGGL((gemm_f32_kernel<X, Y>), grid, dim3(256), 0, st, a, b, out, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu, S > 1 ? kchunk : 0, (int64_t)0, (int64_t)0, (int64_t)0)
   if (akc && bkc) LAUNCH(true, true);
   else if (akc) LAUNCH(true, false);
   else if (bkc) LAUNCH(false, true);
@@ -143,6 +160,23 @@ static int gemm_f32(const float* a, const float* b, float* c, const float* bias,
   }
   return MMSKIN_OK;
 }
+
+// out[k][n] = in[n][k]  (rows x cols -> cols x rows), 32x32 tiles through LDS
+__global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[i][threadIdx.x] = in[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(int64_t)c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+// Linear layers over batch x tokens rows with 64-multiple widths run on the exact-f32 implicit-GEMM conv kernels
+static inline bool linear_big(int M, int K, int N) { return M >= 2048 && K % 64 == 0 && N % 64 == 0; }
 
 __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -623,12 +657,62 @@ __global__ void pool_gap_bwd_kernel(const float* dy, const int32_t* idx, float* 
   }
 }
 
+// ------------------------------------------------------------------ row softmax / GELU (BERT-style encoder layers)
+// y[r][j] = softmax_j(x[r][j] * scale + mask_add[b][j]), b = r / rows_per_batch; one wave per row
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask_add,
+                                                          float* __restrict__ y, int64_t rows, int L, int64_t rows_per_batch,
+                                                          float scale) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + r * L;
+  const float* mk = mask_add ? mask_add + (r / rows_per_batch) * L : nullptr;
+  float mx = -INFINITY;
+  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, xr[j] * scale + (mk ? mk[j] : 0.f));
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < L; j += 64) sum += expf(xr[j] * scale + (mk ? mk[j] : 0.f) - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int j = lane; j < L; j += 64) y[r * L + j] = expf(xr[j] * scale + (mk ? mk[j] : 0.f) - mx) * inv;
+}
+// dx = (dy - sum_j dy*y) * y * scale
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ dx, int64_t rows, int L, float scale) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float dot = 0.f;
+  for (int j = lane; j < L; j += 64) dot += dy[r * L + j] * y[r * L + j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < L; j += 64) dx[r * L + j] = (dy[r * L + j] - dot) * y[r * L + j] * scale;
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n, int64_t nb) {
+  EW_LOOP(n) y[i] = a[i] + b[i % nb];   // b broadcasts over the leading dimension when nb < n
+}
+__global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  EW_LOOP(n) y[i] = 0.5f * x[i] * (1.f + erff(x[i] * 0.70710678118654752f));
+}
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
+  EW_LOOP(n) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * v * v);
+    dx[i] = dy[i] * (cdf + v * pdf);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
 int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
                           void* stream) {
   ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+  if (linear_big(M, K, N)) {   // tokens x hidden GEMMs of the text encoders: the exact-f32 implicit-GEMM kernel as a 1x1 conv
+    ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+    FwdFuse f; f.bias = b; f.relu = relu != 0;
+    return launch_conv_fwd<float>(s, x, w, y, nullptr, nullptr, ST(stream), (b || relu) ? &f : nullptr);
+  }
   return gemm_f32(x, w, y, b, M, N, K, K, 1, K, 1, N, relu, ST(stream));
 }
 
@@ -644,6 +728,24 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     g = dy_scratch;
   }
   int rc;
+  if (linear_big(M, K, N)) {
+    ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+    const size_t wt_bytes = align_up((size_t)N * K * sizeof(float), 256);
+    float* scratch = head_scratch(wt_bytes + conv_wgrad_slab_bytes(s));
+    if (!scratch) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    if (dx) {
+      ARG_CHECK(w, "linear_backward: w required for dx");
+      hipLaunchKernelGGL(transpose_f32_kernel, dim3(ceil_div(K, 32), ceil_div(N, 32)), dim3(32, 8), 0, st, w, scratch, N, K);
+      HIP_CHECK_RET(hipGetLastError());
+      if ((rc = launch_conv_dgrad<float>(s, g, scratch, dx, (const float*)nullptr, st))) return rc;
+    }
+    if (dw) {
+      ARG_CHECK(x, "linear_backward: x required for dw");
+      if ((rc = launch_conv_wgrad<float>(s, g, x, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scratch) + wt_bytes), dw, st))) return rc;
+    }
+    if (db && (rc = colsum(g, db, M, N, st))) return rc;
+    return MMSKIN_OK;
+  }
   if (dx) {  // dx[m][k] = sum_n g[m][n] * w[n][k]
     ARG_CHECK(w, "linear_backward: w required for dx");
     if ((rc = gemm_f32(g, w, dx, nullptr, M, K, N, N, 1, 1, K, K, 0, st))) return rc;
@@ -761,6 +863,36 @@ int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const fl
                      dfeat, dz, dt1, dt2, NC, HW);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
+}
+
+int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t sam, int64_t sak, int64_t sab,
+               int64_t sbn, int64_t sbk, int64_t sbb, int64_t ldc, int64_t scb, void* stream) {
+  ARG_CHECK(a && b && c && batch > 0 && M > 0 && N > 0 && K > 0, "bmm: bad argument");
+  if (batch == 1) return gemm_f32(a, b, c, nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 0, ST(stream));
+  ARG_CHECK(batch <= 65535, "bmm: batch %d exceeds the grid limit", batch);
+  return gemm_f32(a, b, c, nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 0, ST(stream), batch, sab, sbb, scb);
+}
+int mmskin_softmax_forward(const float* x, const float* mask_add, float* y, int64_t rows, int L, int64_t rows_per_batch,
+                           float scale, void* stream) {
+  ARG_CHECK(x && y && rows > 0 && L > 0 && rows_per_batch > 0, "softmax_forward: bad argument");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, mask_add, y, rows, L,
+                     rows_per_batch, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_softmax_backward(const float* dy, const float* y, float* dx, int64_t rows, int L, float scale, void* stream) {
+  ARG_CHECK(dy && y && dx && rows > 0 && L > 0, "softmax_backward: bad argument");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dy, y, dx, rows, L, scale);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream) {
+  ARG_CHECK(a && b && y && n > 0 && nb > 0 && n % nb == 0, "add: bad argument");
+  EW_LAUNCH(add_kernel, n, a, b, y, n, nb);
+}
+int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream) { EW_LAUNCH(gelu_fwd_kernel, n, x, y, n); }
+int mmskin_gelu_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  EW_LAUNCH(gelu_bwd_kernel, n, dy, x, dx, n);
 }
 
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,

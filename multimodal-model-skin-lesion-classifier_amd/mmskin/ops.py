@@ -255,14 +255,77 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
-def attention(q, k, v, dropout_p=0.0, training=False):
-    if not training or dropout_p <= 0.0:
-        return AttentionFn.apply(q, k, v, 0.0, 0, 0)
-    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-    B, H, L, _ = q.shape
-    _dropout_counter[0] += B * H * L * L
-    return AttentionFn.apply(q, k, v, dropout_p, seed, _dropout_counter[0])
+def _bmm(a, b, c, batch, M, N, K, sam, sak, sab, sbn, sbk, sbb, ldc, scb):
+    call("mmskin_bmm", ptr(a), ptr(b), ptr(c), batch, M, N, K, sam, sak, sab, sbn, sbk, sbb, ldc, scb, stream())
 
+
+class LongAttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(Dh) + mask) v for sequences whose score matrix does not fit one workgroup's LDS
+    (BERT: L = 512): strided batched GEMMs + a row-softmax kernel, the probabilities kept for backward.
+    q, k, v [B, H, L, Dh]; mask_add [B, L] additive key mask or None; dropout on the probabilities when drop_p > 0."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_add, drop_p, seed, offset):
+        _need_gpu(q, "attention")
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        B, H, L, Dh = q.shape
+        BH = B * H
+        scores = torch.empty((B, H, L, L), device=q.device, dtype=torch.float32)
+        _bmm(q, k, scores, BH, L, L, Dh, Dh, 1, L * Dh, Dh, 1, L * Dh, L, L * L)
+        probs = torch.empty_like(scores)
+        m = _f32c(mask_add) if mask_add is not None else None
+        call("mmskin_softmax_forward", ptr(scores), ptr(m) if m is not None else None, ptr(probs), BH * L, L, H * L,
+             1.0 / Dh ** 0.5, stream())
+        del scores
+        dmask = None
+        pd = probs
+        if drop_p > 0.0:
+            pd = torch.empty_like(probs)
+            dmask = torch.empty(probs.shape, device=q.device, dtype=torch.uint8)
+            call("mmskin_dropout_forward", ptr(probs), ptr(pd), ptr(dmask), probs.numel(), float(drop_p), int(seed), int(offset), stream())
+        o = torch.empty_like(q)
+        _bmm(pd, v, o, BH, L, Dh, L, L, 1, L * L, 1, Dh, L * Dh, Dh, L * Dh)          # o[i][d] = sum_j pd[i][j] v[j][d]
+        ctx.save_for_backward(q, k, v, probs, pd if drop_p > 0.0 else None, dmask)
+        ctx.drop_p = float(drop_p)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, probs, pd, dmask = ctx.saved_tensors
+        B, H, L, Dh = q.shape
+        BH = B * H
+        dO = _f32c(dO)
+        pdrop = pd if pd is not None else probs
+        dv = torch.empty_like(v)
+        _bmm(pdrop, dO, dv, BH, L, Dh, L, 1, L, L * L, 1, Dh, L * Dh, Dh, L * Dh)        # dv[j][d] = sum_i pd[i][j] dO[i][d]
+        dp = torch.empty_like(probs)
+        _bmm(dO, v, dp, BH, L, L, Dh, Dh, 1, L * Dh, Dh, 1, L * Dh, L, L * L)           # dp[i][j] = sum_d dO[i][d] v[j][d]
+        if dmask is not None:
+            dp2 = torch.empty_like(dp)
+            call("mmskin_dropout_backward", ptr(dp), ptr(dmask), ptr(dp2), dp.numel(), ctx.drop_p, stream())
+            dp = dp2
+        ds = torch.empty_like(dp)
+        call("mmskin_softmax_backward", ptr(dp), ptr(probs), ptr(ds), BH * L, L, 1.0 / Dh ** 0.5, stream())
+        del dp
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        _bmm(ds, k, dq, BH, L, Dh, L, L, 1, L * L, 1, Dh, L * Dh, Dh, L * Dh)            # dq[i][d] = sum_j ds[i][j] k[j][d]
+        _bmm(ds, q, dk, BH, L, Dh, L, 1, L, L * L, 1, Dh, L * Dh, Dh, L * Dh)            # dk[j][d] = sum_i ds[i][j] q[i][d]
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None):
+    B, H, L, _ = q.shape
+    p = dropout_p if training else 0.0
+    seed = offset = 0
+    if p > 0.0:
+        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        _dropout_counter[0] += B * H * L * L
+        offset = _dropout_counter[0]
+    if mask_add is not None or L * L * 4 > 64 * 1024:
+        return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset)
+    if p <= 0.0:
+        return AttentionFn.apply(q, k, v, 0.0, 0, 0)
+    return AttentionFn.apply(q, k, v, p, seed, offset)
 
 
 class MDNetFuseFn(torch.autograd.Function):
@@ -291,6 +354,50 @@ class MDNetFuseFn(torch.autograd.Function):
 
 
 mdnet_fuse = MDNetFuseFn.apply
+
+
+class AddFn(torch.autograd.Function):
+    """a + b with b broadcast over a's leading dimensions (residual sums, position embeddings)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, "add")
+        a, b = _f32c(a), _f32c(b)
+        y = torch.empty_like(a)
+        call("mmskin_add", ptr(a), ptr(b), ptr(y), a.numel(), b.numel(), stream())
+        ctx.bshape = b.shape
+        ctx.lead = a.numel() // b.numel()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = dy if ctx.lead == 1 else dy.reshape(ctx.lead, -1).sum(0).reshape(ctx.bshape)
+        return dy, db
+
+
+add = AddFn.apply
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "gelu")
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call("mmskin_gelu_forward", ptr(x), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        call("mmskin_gelu_backward", ptr(dy), ptr(x), ptr(dx), x.numel(), stream())
+        return dx
+
+
+gelu = GeluFn.apply
 
 
 class EmbeddingFn(torch.autograd.Function):

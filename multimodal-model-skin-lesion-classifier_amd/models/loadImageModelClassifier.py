@@ -87,10 +87,16 @@ class loadModels:
     @staticmethod
     def loadTextModelEncoder(text_model_encoder: str, train_mode: str = "frozen_weights"):
         """reference :162-203 -> (model, output_dim, output_dim)."""
-        if text_model_encoder in ["bert-base-uncased", "gpt2"]:
+        if text_model_encoder == "bert-base-uncased":
+            from hip_bert import HipBertModel
+            model = HipBertModel()                      # random init; load a HuggingFace state_dict for trained weights
+            output_dim = model.config.hidden_size
+            for p in model.parameters():                # reference :174-179
+                p.requires_grad = train_mode == "unfrozen_weights"
+            return model, output_dim, output_dim
+        elif text_model_encoder == "gpt2":
             raise NotImplementedError(
-                f"Text encoder '{text_model_encoder}' is accepted by the reference but has no MI355X kernels "
-                "yet (see DESIGN.md, scope table).")
+                "Text encoder 'gpt2' is accepted by the reference but has no MI355X kernels yet (see DESIGN.md, scope table).")
         elif text_model_encoder == "tab-transformer":
             categorical_cardinalities = [10] * 82
             output_dim = 85

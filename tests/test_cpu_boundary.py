@@ -162,3 +162,13 @@ def test_efficientnet_key_layout_and_plan():
         assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
         assert not any(p.requires_grad for p in m.parameters())
         assert m._plan_for(2, 64, 64, None).feat_dim == dim      # parameter / buffer layout checked against the C plan inside
+
+
+def test_bert_key_layout_matches_transformers():
+    transformers = __import__("pytest").importorskip("transformers")
+    from models.hip_bert import HipBertModel
+    cfg = dict(vocab_size=50, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64, max_position_embeddings=16)
+    hf = transformers.BertModel(transformers.BertConfig(**cfg))
+    hip = HipBertModel(**cfg)
+    assert {k: tuple(v.shape) for k, v in hip.state_dict().items()} == {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+    hip.load_state_dict(hf.state_dict(), strict=True)
