@@ -89,3 +89,102 @@ class OracleMetaNetModel(nn.Module):
     def forward(self, image, metadata):
         f = self.metanet(self.backbone(image), metadata)
         return self.classifier(F.adaptive_avg_pool2d(f, 1).flatten(1))
+
+
+VIT_CONFIGS = {"vit_tiny_patch16_224": (192, 12, 3), "vit_small_patch16_224": (384, 12, 6),
+               "vit_base_patch16_224": (768, 12, 12), "vit_large_patch16_224": (1024, 24, 16)}
+
+
+class _ViTAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, L, E = x.shape
+        qkv = self.qkv(x).reshape(B, L, 3, self.num_heads, E // self.num_heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2])
+        return self.proj(o.transpose(1, 2).reshape(B, L, E))
+
+
+class _ViTMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _ViTBlock(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _ViTAttention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _ViTMlp(dim, dim * 4)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class _ViTPatchEmbed(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, 16, 16)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class OracleViT(nn.Module):
+    """timm VisionTransformer (vit_*_patch16_224, num_classes=0) restated: pre-norm blocks, qkv bias, LayerNorm eps 1e-6,
+    exact GELU, class token + learned position embedding.  PARITY UNPINNED against timm (absent); keys follow it."""
+
+    def __init__(self, name):
+        super().__init__()
+        dim, depth, heads = VIT_CONFIGS[name]
+        self.num_features = dim
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, 197, dim) * 0.02)
+        self.patch_embed = _ViTPatchEmbed(dim)
+        self.blocks = nn.Sequential(*[_ViTBlock(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed[:, :x.shape[1] + 1]
+        return self.norm(self.blocks(x))
+
+    def forward(self, x):
+        return self.forward_features(x)[:, 0]
+
+
+class OracleLiwTERM(nn.Module):
+    """liwtermModel.py:6-102."""
+
+    def __init__(self, num_classes, meta_dim, image_encoder="vit_large_patch16_224", unfreeze_backbone=False, dropout=0.3):
+        super().__init__()
+        self.visual = OracleViT(image_encoder)
+        if not unfreeze_backbone:
+            for p in self.visual.parameters():
+                p.requires_grad = False
+        d = self.visual.num_features
+        self.visual_proj = nn.Sequential(nn.Linear(d, 4096), nn.LayerNorm(4096), nn.ReLU(), nn.Dropout(dropout))
+        self.meta_fc = nn.Sequential(nn.LayerNorm(meta_dim), nn.Linear(meta_dim, 1024), nn.ReLU())
+        c = 4096 + 1024
+        self.slm = nn.Sequential(
+            nn.LayerNorm(c), nn.ReLU(), nn.Dropout(dropout),
+            nn.Linear(c, 2048), nn.LayerNorm(2048), nn.ReLU(), nn.Dropout(dropout),
+            nn.Linear(2048, 1024), nn.LayerNorm(1024), nn.ReLU(), nn.Dropout(dropout),
+            nn.Linear(1024, 512), nn.LayerNorm(512), nn.ReLU(), nn.Dropout(dropout),
+            nn.Linear(512, num_classes))
+
+    def forward(self, image, metadata):
+        v = self.visual.forward_features(image)[:, 0]
+        return self.slm(torch.cat([self.visual_proj(v), self.meta_fc(metadata)], dim=1))

@@ -138,11 +138,14 @@ def gen_alt_models(ref):
     fusion code and the state_dict key layout, not the third-party backbone arithmetic."""
     import importlib
     import sys
-    from .altmodels import OracleResNetFeatureMaps
+    from .altmodels import OracleResNetFeatureMaps, OracleViT
     from .backbones import OracleDenseNet169
     sys.modules["torchvision.models"].densenet169 = lambda pretrained=True: OracleDenseNet169()
-    sys.modules["timm"].create_model = lambda name, pretrained=True, num_classes=0, global_pool="": \
-        OracleResNetFeatureMaps({"resnet50": "resnet-50", "resnet18": "resnet-18"}[name])
+    def create_model(name, pretrained=True, num_classes=0, global_pool=""):
+        if name.startswith("vit_"):
+            return OracleViT(name)
+        return OracleResNetFeatureMaps({"resnet50": "resnet-50", "resnet18": "resnet-18"}[name])
+    sys.modules["timm"].create_model = create_model
     out = {}
     img, meta, lab = det_inputs(3, 64, 20, 6)
     mdnet = importlib.import_module("multimodalMDNet").MDNet(meta_dim=20, num_classes=6, unfreeze_weights=True)
@@ -152,6 +155,11 @@ def gen_alt_models(ref):
                                                          unfreeze_weights=True)
     out["metanet"] = step_record(det_init_(mn), img, meta, lab)
     out["metanet"]["keys"] = list(mn.state_dict().keys())
+    img224, meta, lab = det_inputs(2, 224, 20, 6)
+    lw = importlib.import_module("liwtermModel").LiwTERM(num_classes=6, meta_dim=20, image_encoder="vit_tiny_patch16_224",
+                                                         pretrained=False, unfreeze_backbone=True)
+    out["liwterm"] = step_record(det_init_(lw), img224, meta, lab)
+    out["liwterm"]["keys"] = list(lw.state_dict().keys())
     return out
 
 

@@ -172,3 +172,14 @@ def test_bert_key_layout_matches_transformers():
     hip = HipBertModel(**cfg)
     assert {k: tuple(v.shape) for k, v in hip.state_dict().items()} == {k: tuple(v.shape) for k, v in hf.state_dict().items()}
     hip.load_state_dict(hf.state_dict(), strict=True)
+
+
+def test_liwterm_drop_in_key_layout():
+    from helpers import golden
+    from models.liwtermModel import LiwTERM
+    from oracle.altmodels import OracleLiwTERM
+    hip = LiwTERM(num_classes=6, meta_dim=20, image_encoder="vit_tiny_patch16_224", pretrained=False, unfreeze_backbone=True)
+    ora = OracleLiwTERM(num_classes=6, meta_dim=20, image_encoder="vit_tiny_patch16_224", unfreeze_backbone=True)
+    assert list(hip.state_dict().keys()) == golden("alt_models")["liwterm"]["keys"]
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    assert not any(p.requires_grad for p in LiwTERM(6, 20, image_encoder="vit_tiny_patch16_224").visual.parameters())

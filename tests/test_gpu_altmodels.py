@@ -12,7 +12,7 @@ from gpu_util import DEV, rel_err
 from oracle.detinit import det_init_, det_inputs, det_tensor
 
 pytestmark = pytest.mark.gpu
-BACKBONE = ("feature_extractor.", "backbone.")
+BACKBONE = ("feature_extractor.", "backbone.", "visual.")
 
 
 def _build(which):
@@ -20,15 +20,18 @@ def _build(which):
     if which == "mdnet":
         from models.multimodalMDNet import MDNet
         return MDNet(meta_dim=20, num_classes=6, unfreeze_weights=True, device=DEV)
+    if which == "liwterm":
+        from models.liwtermModel import LiwTERM
+        return LiwTERM(num_classes=6, meta_dim=20, image_encoder="vit_tiny_patch16_224", pretrained=False, unfreeze_backbone=True)
     from models.metanet import MetaNetModel
     return MetaNetModel(meta_dim=20, num_classes=6, image_encoder="resnet18", unfreeze_weights=True)
 
 
-@pytest.mark.parametrize("which", ["mdnet", "metanet"])
+@pytest.mark.parametrize("which", ["mdnet", "metanet", "liwterm"])
 def test_alternate_model_matches_reference_fixture(which):
     gold = golden("alt_models")[which]
     model = det_init_(_build(which)).to(DEV)
-    img, meta, lab = det_inputs(3, 64, 20, 6)
+    img, meta, lab = det_inputs(2, 224, 20, 6) if which == "liwterm" else det_inputs(3, 64, 20, 6)
     rec = train_step_record(model, img.to(DEV), meta.to(DEV), lab.to(DEV), device=DEV)
     check_record_against_golden(rec, gold, 1e-3, 1e-5, skip_prefix=BACKBONE)        # logits, loss, head gradients, Adam
     for k, g in gold["grads"].items():                                            # backbone: noise-aware (see CPU test)
@@ -76,3 +79,16 @@ def test_mdnet_bf16_and_frozen_backbone():
     assert all(p.grad is None for p in model.feature_extractor.parameters())
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters()
                if not n.startswith("feature_extractor."))
+
+
+def test_vit_large_backbone_runs_frozen():
+    """LiwTERM's default: frozen vit_large_patch16_224 (304 M parameters), trainable projection + SLM head."""
+    from models.liwtermModel import LiwTERM
+    model = LiwTERM(num_classes=6, meta_dim=20).to(DEV).train()
+    assert sum(p.numel() for p in model.visual.parameters()) == 303301632          # timm vit_large_patch16_224, num_classes=0
+    img, meta, lab = det_inputs(2, 224, 20, 6)
+    loss = F.cross_entropy(model(img.to(DEV), meta.to(DEV)), lab.to(DEV))
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(p.grad is None for p in model.visual.parameters())
+    assert all(p.grad is not None for n, p in model.named_parameters() if not n.startswith("visual."))

@@ -70,21 +70,25 @@ def test_blocks():
     assert torch.allclose(y.double(), torch.tensor(gold["tab_transformer"]["y"], dtype=torch.float64), rtol=1e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("which", ["mdnet", "metanet"])
+@pytest.mark.parametrize("which", ["mdnet", "metanet", "liwterm"])
 def test_alternate_models_match_reference_classes(which):
     """MD-Net / MetaNet+ResNet restatements vs the fixture recorded through the reference's own classes
     (tests/golden/alt_models.json; backbone constructors replaced as documented in oracle/gen_golden.py)."""
-    from oracle.altmodels import OracleMDNet, OracleMetaNetModel
+    from oracle.altmodels import OracleLiwTERM, OracleMDNet, OracleMetaNetModel
     gold = golden("alt_models")[which]
+    inputs = det_inputs(3, 64, 20, 6)
     if which == "mdnet":
         model = OracleMDNet(meta_dim=20, num_classes=6, unfreeze_weights=True)
-    else:
+    elif which == "metanet":
         model = OracleMetaNetModel(meta_dim=20, num_classes=6, image_encoder="resnet18", unfreeze_weights=True)
+    else:
+        model = OracleLiwTERM(num_classes=6, meta_dim=20, image_encoder="vit_tiny_patch16_224", unfreeze_backbone=True)
+        inputs = det_inputs(2, 224, 20, 6)
     assert list(model.state_dict().keys()) == gold["keys"]
-    rec = train_step_record(det_init_(model), *det_inputs(3, 64, 20, 6))
+    rec = train_step_record(det_init_(model), *inputs)
     # backbone gradients of a random-init net amplify fp32 summation-order noise (fixture: 1 thread): the head
     # is held to 1e-3, the backbone to the L1 norm of every gradient within 5 %
-    backbone = ("feature_extractor.", "backbone.")
+    backbone = ("feature_extractor.", "backbone.", "visual.")
     check_record_against_golden(rec, gold, 1e-3, 1e-5, skip_prefix=backbone)
     for k, g in gold["grads"].items():
         if k.startswith(backbone):
