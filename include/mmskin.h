@@ -176,9 +176,15 @@ int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const fl
  * row softmax with scale and an additive per-batch key mask (mask_add [batch][L], may be NULL); exact (erf) GELU. */
 int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t sam, int64_t sak, int64_t sab,
                int64_t sbn, int64_t sbk, int64_t sbb, int64_t ldc, int64_t scb, void* stream);
-int mmskin_softmax_forward(const float* x, const float* mask_add, float* y, int64_t rows, int L, int64_t rows_per_batch,
-                           float scale, void* stream);
+int mmskin_softmax_forward(const float* x, const float* mask_add, const float* bias /* [rows_per_batch][L] or NULL */,
+                           float* y, int64_t rows, int L, int64_t rows_per_batch, float scale, void* stream);
 int mmskin_softmax_backward(const float* dy, const float* y, float* dx, int64_t rows, int L, float scale, void* stream);
+/* pieces of the timm transformer blocks (BEiT: LayerScale residuals, mean pooling over patch tokens, bias gradients) */
+int mmskin_colsum(const float* x, float* out, int M, int N, void* stream);
+int mmskin_scale_add_forward(const float* x, const float* b, const float* gamma, float* y, int64_t n, int C, void* stream);
+int mmskin_scale_mul(const float* dy, const float* v, float* out, int64_t n, int C, int per_channel, void* stream);
+int mmskin_token_mean_forward(const float* x, float* out, int B, int L, int E, int start, void* stream);
+int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E, int start, void* stream);
 /* y = a + b, b broadcast over the leading dimension when nb < n (residual sums, position embeddings) */
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream);
 int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream);

@@ -659,22 +659,49 @@ __global__ void pool_gap_bwd_kernel(const float* dy, const int32_t* idx, float* 
 
 // ------------------------------------------------------------------ row softmax / GELU (BERT-style encoder layers)
 // y[r][j] = softmax_j(x[r][j] * scale + mask_add[b][j]), b = r / rows_per_batch; one wave per row
+// bias (optional): [rows_per_batch][L] added to every batch's scores (per-head relative-position bias of BEiT)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask_add,
-                                                          float* __restrict__ y, int64_t rows, int L, int64_t rows_per_batch,
-                                                          float scale) {
+                                                          const float* __restrict__ bias, float* __restrict__ y, int64_t rows,
+                                                          int L, int64_t rows_per_batch, float scale) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* xr = x + r * L;
   const float* mk = mask_add ? mask_add + (r / rows_per_batch) * L : nullptr;
+  const float* bs = bias ? bias + (r % rows_per_batch) * L : nullptr;
   float mx = -INFINITY;
-  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, xr[j] * scale + (mk ? mk[j] : 0.f));
+  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f));
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int j = lane; j < L; j += 64) sum += expf(xr[j] * scale + (mk ? mk[j] : 0.f) - mx);
+  for (int j = lane; j < L; j += 64) sum += expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx);
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
-  for (int j = lane; j < L; j += 64) y[r * L + j] = expf(xr[j] * scale + (mk ? mk[j] : 0.f) - mx) * inv;
+  for (int j = lane; j < L; j += 64) y[r * L + j] = expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx) * inv;
+}
+// y = x + gamma[c] * b  (LayerScale residual), and its pieces backward
+__global__ void scale_add_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ gamma,
+                                     float* __restrict__ y, int64_t n, int C) {
+  EW_LOOP(n) y[i] = x[i] + gamma[i % C] * b[i];
+}
+__global__ void scale_mul_kernel(const float* __restrict__ dy, const float* __restrict__ v, float* __restrict__ out, int64_t n, int C,
+                                 int per_channel) {
+  EW_LOOP(n) out[i] = dy[i] * (per_channel ? v[i % C] : v[i]);
+}
+// out[b][e] = mean over tokens [start, L) of x[b][t][e]; backward spreads dout / (L - start)
+__global__ void token_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int L, int E, int start) {
+  EW_LOOP((int64_t)B * E) {
+    const int e = (int)(i % E); const int64_t b = i / E;
+    float s2 = 0.f;
+    for (int t = start; t < L; ++t) s2 += x[(b * L + t) * E + e];
+    out[i] = s2 / (float)(L - start);
+  }
+}
+__global__ void token_mean_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B, int L, int E, int start) {
+  EW_LOOP((int64_t)B * L * E) {
+    const int e = (int)(i % E); const int64_t t2 = i / E;
+    const int t = (int)(t2 % L); const int64_t b = t2 / L;
+    dx[i] = t >= start ? dout[b * E + e] / (float)(L - start) : 0.f;
+  }
 }
 // dx = (dy - sum_j dy*y) * y * scale
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -872,10 +899,10 @@ int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N
   ARG_CHECK(batch <= 65535, "bmm: batch %d exceeds the grid limit", batch);
   return gemm_f32(a, b, c, nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 0, ST(stream), batch, sab, sbb, scb);
 }
-int mmskin_softmax_forward(const float* x, const float* mask_add, float* y, int64_t rows, int L, int64_t rows_per_batch,
-                           float scale, void* stream) {
+int mmskin_softmax_forward(const float* x, const float* mask_add, const float* bias, float* y, int64_t rows, int L,
+                           int64_t rows_per_batch, float scale, void* stream) {
   ARG_CHECK(x && y && rows > 0 && L > 0 && rows_per_batch > 0, "softmax_forward: bad argument");
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, mask_add, y, rows, L,
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, mask_add, bias, y, rows, L,
                      rows_per_batch, scale);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -885,6 +912,27 @@ int mmskin_softmax_backward(const float* dy, const float* y, float* dx, int64_t 
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), dy, y, dx, rows, L, scale);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
+}
+int mmskin_colsum(const float* x, float* out, int M, int N, void* stream) {
+  ARG_CHECK(x && out && M > 0 && N > 0, "colsum: bad argument");
+  return colsum(x, out, M, N, ST(stream));
+}
+int mmskin_scale_add_forward(const float* x, const float* b, const float* gamma, float* y, int64_t n, int C, void* stream) {
+  ARG_CHECK(x && b && gamma && y && n > 0 && C > 0, "scale_add_forward: bad argument");
+  EW_LAUNCH(scale_add_fwd_kernel, n, x, b, gamma, y, n, C);
+}
+/* out = dy * v, v per channel (per_channel = 1: v[C]) or elementwise (v[n]) */
+int mmskin_scale_mul(const float* dy, const float* v, float* out, int64_t n, int C, int per_channel, void* stream) {
+  ARG_CHECK(dy && v && out && n > 0 && C > 0, "scale_mul: bad argument");
+  EW_LAUNCH(scale_mul_kernel, n, dy, v, out, n, C, per_channel);
+}
+int mmskin_token_mean_forward(const float* x, float* out, int B, int L, int E, int start, void* stream) {
+  ARG_CHECK(x && out && B > 0 && L > start && E > 0, "token_mean_forward: bad argument");
+  EW_LAUNCH(token_mean_fwd_kernel, (int64_t)B * E, x, out, B, L, E, start);
+}
+int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E, int start, void* stream) {
+  ARG_CHECK(dout && dx && B > 0 && L > start && E > 0, "token_mean_backward: bad argument");
+  EW_LAUNCH(token_mean_bwd_kernel, (int64_t)B * L * E, dout, dx, B, L, E, start);
 }
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream) {
   ARG_CHECK(a && b && y && n > 0 && nb > 0 && n % nb == 0, "add: bad argument");

@@ -265,7 +265,7 @@ class LongAttentionFn(torch.autograd.Function):
     q, k, v [B, H, L, Dh]; mask_add [B, L] additive key mask or None; dropout on the probabilities when drop_p > 0."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask_add, drop_p, seed, offset):
+    def forward(ctx, q, k, v, mask_add, drop_p, seed, offset, bias=None):
         _need_gpu(q, "attention")
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
         B, H, L, Dh = q.shape
@@ -274,8 +274,10 @@ class LongAttentionFn(torch.autograd.Function):
         _bmm(q, k, scores, BH, L, L, Dh, Dh, 1, L * Dh, Dh, 1, L * Dh, L, L * L)
         probs = torch.empty_like(scores)
         m = _f32c(mask_add) if mask_add is not None else None
-        call("mmskin_softmax_forward", ptr(scores), ptr(m) if m is not None else None, ptr(probs), BH * L, L, H * L,
-             1.0 / Dh ** 0.5, stream())
+        bs = _f32c(bias) if bias is not None else None                              # [H, L, L], shared by the batch
+        call("mmskin_softmax_forward", ptr(scores), ptr(m) if m is not None else None, ptr(bs) if bs is not None else None,
+             ptr(probs), BH * L, L, H * L, 1.0 / Dh ** 0.5, stream())
+        ctx.has_bias = bias is not None
         del scores
         dmask = None
         pd = probs
@@ -310,10 +312,15 @@ class LongAttentionFn(torch.autograd.Function):
         dq, dk = torch.empty_like(q), torch.empty_like(k)
         _bmm(ds, k, dq, BH, L, Dh, L, L, 1, L * L, 1, Dh, L * Dh, Dh, L * Dh)            # dq[i][d] = sum_j ds[i][j] k[j][d]
         _bmm(ds, q, dk, BH, L, Dh, L, 1, L, L * L, 1, Dh, L * Dh, Dh, L * Dh)            # dk[j][d] = sum_i ds[i][j] q[i][d]
-        return dq, dk, dv, None, None, None, None
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[7]:       # d/d(bias) = d/d(scaled scores) summed over the batch = ds / scale
+            dbias = torch.empty((H, L, L), device=q.device, dtype=torch.float32)
+            call("mmskin_colsum", ptr(ds), ptr(dbias), B, H * L * L, stream())
+            dbias.mul_(Dh ** 0.5)
+        return dq, dk, dv, None, None, None, None, dbias
 
 
-def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None):
+def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None):
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
     seed = offset = 0
@@ -321,8 +328,8 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None):
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         _dropout_counter[0] += B * H * L * L
         offset = _dropout_counter[0]
-    if mask_add is not None or L * L * 4 > 64 * 1024:
-        return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset)
+    if mask_add is not None or bias is not None or L * L * 4 > 64 * 1024:
+        return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset, bias)
     if p <= 0.0:
         return AttentionFn.apply(q, k, v, 0.0, 0, 0)
     return AttentionFn.apply(q, k, v, p, seed, offset)
@@ -376,6 +383,60 @@ class AddFn(torch.autograd.Function):
 
 
 add = AddFn.apply
+
+
+class ScaleAddFn(torch.autograd.Function):
+    """x + gamma[c] * b   (timm LayerScale residual: x + gamma_1 * attn(norm1(x)))."""
+
+    @staticmethod
+    def forward(ctx, x, b, gamma):
+        _need_gpu(x, "scale_add")
+        x, b, gamma = _f32c(x), _f32c(b), _f32c(gamma)
+        y = torch.empty_like(x)
+        call("mmskin_scale_add_forward", ptr(x), ptr(b), ptr(gamma), ptr(y), x.numel(), gamma.numel(), stream())
+        ctx.save_for_backward(b, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        C = gamma.numel()
+        db = torch.empty_like(dy)
+        call("mmskin_scale_mul", ptr(dy), ptr(gamma), ptr(db), dy.numel(), C, 1, stream())
+        prod = torch.empty_like(dy)
+        call("mmskin_scale_mul", ptr(dy), ptr(b), ptr(prod), dy.numel(), C, 0, stream())
+        dgamma = torch.empty_like(gamma)
+        call("mmskin_colsum", ptr(prod), ptr(dgamma), dy.numel() // C, C, stream())
+        return dy, db, dgamma
+
+
+scale_add = ScaleAddFn.apply
+
+
+class TokenMeanFn(torch.autograd.Function):
+    """mean over tokens [start, L) of x [B, L, E]   (timm global_pool='avg' over the patch tokens)."""
+
+    @staticmethod
+    def forward(ctx, x, start):
+        _need_gpu(x, "token_mean")
+        x = _f32c(x)
+        B, L, E = x.shape
+        out = torch.empty((B, E), device=x.device, dtype=torch.float32)
+        call("mmskin_token_mean_forward", ptr(x), ptr(out), B, L, E, int(start), stream())
+        ctx.dims = (B, L, E, int(start))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, L, E, start = ctx.dims
+        dout = _f32c(dout)
+        dx = torch.empty((B, L, E), device=dout.device, dtype=torch.float32)
+        call("mmskin_token_mean_backward", ptr(dout), ptr(dx), B, L, E, start, stream())
+        return dx, None
+
+
+token_mean = TokenMeanFn.apply
 
 
 class GeluFn(torch.autograd.Function):

@@ -76,6 +76,23 @@ class loadModels:
                     p.requires_grad = True
             else:
                 loadModels.set_backbone_train_mode(model, backbone_train_mode)
+        elif cnn_model_name.startswith(("beitv2_", "vit_")):
+            # the reference's generic timm branch (:117-152): create_model(name) + reset_classifier(0), F = num_features,
+            # "partial" unfreezes the last block
+            if cnn_model_name.startswith("beitv2_"):
+                from hip_beit import HipBeit
+                model = HipBeit(cnn_model_name)
+            else:
+                from hip_vit import HipVisionTransformer
+                model = HipVisionTransformer(cnn_model_name)
+            cnn_dim_output = model.num_features
+            if backbone_train_mode == "partial":
+                for p in model.parameters():
+                    p.requires_grad = False
+                for p in model.blocks[-1].parameters():
+                    p.requires_grad = True
+            else:
+                loadModels.set_backbone_train_mode(model, backbone_train_mode)
         elif cnn_model_name in _KNOWN_WITHOUT_PLAN:
             raise NotImplementedError(
                 f"Backbone '{cnn_model_name}' is accepted by the reference but has no MI355X plan yet "

@@ -188,3 +188,75 @@ class OracleLiwTERM(nn.Module):
     def forward(self, image, metadata):
         v = self.visual.forward_features(image)[:, 0]
         return self.slm(torch.cat([self.visual_proj(v), self.meta_fc(metadata)], dim=1))
+
+
+class _BeitAttention(nn.Module):
+    def __init__(self, dim, heads, ws):
+        super().__init__()
+        self.num_heads = heads
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2 + 3, heads))
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+        self.register_buffer("k_bias", torch.zeros(dim), persistent=False)
+        num = (2 * ws - 1) ** 2 + 3
+        coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+        rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += ws - 1
+        rel[:, :, 1] += ws - 1
+        rel[:, :, 0] *= 2 * ws - 1
+        idx = torch.zeros((ws * ws + 1,) * 2, dtype=torch.long)
+        idx[1:, 1:] = rel.sum(-1)
+        idx[0, 0:] = num - 3
+        idx[0:, 0] = num - 2
+        idx[0, 0] = num - 1
+        self.register_buffer("relative_position_index", idx, persistent=False)
+
+    def forward(self, x):
+        B, L, E = x.shape
+        H = self.num_heads
+        qkv = F.linear(x, self.qkv.weight, torch.cat([self.q_bias, self.k_bias.to(x.dtype), self.v_bias]))
+        q, k, v = qkv.reshape(B, L, 3, H, E // H).permute(2, 0, 3, 1, 4)
+        attn = (q * (E // H) ** -0.5) @ k.transpose(-2, -1)
+        attn = attn + self.relative_position_bias_table[self.relative_position_index.view(-1)].view(L, L, H).permute(2, 0, 1)
+        return self.proj((attn.softmax(dim=-1) @ v).transpose(1, 2).reshape(B, L, E))
+
+
+class _BeitBlock(nn.Module):
+    def __init__(self, dim, heads, ws, init_values):
+        super().__init__()
+        self.gamma_1 = nn.Parameter(init_values * torch.ones(dim))
+        self.gamma_2 = nn.Parameter(init_values * torch.ones(dim))
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _BeitAttention(dim, heads, ws)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _ViTMlp(dim, dim * 4)
+
+    def forward(self, x):
+        x = x + self.gamma_1 * self.attn(self.norm1(x))
+        return x + self.gamma_2 * self.mlp(self.norm2(x))
+
+
+BEIT_CONFIGS = {"beitv2_base_patch16_224": (768, 12, 12), "beitv2_large_patch16_224": (1024, 24, 16), "beitv2_tiny_test": (64, 2, 4)}
+
+
+class OracleBeit(nn.Module):
+    """timm Beit (beitv2_*_patch16_224 after reset_classifier(0)) restated: no absolute position embedding, per-block
+    relative position bias, q/v bias, LayerScale, mean pooling over patch tokens + fc_norm.  PARITY UNPINNED against timm."""
+
+    def __init__(self, name, init_values=1e-5):
+        super().__init__()
+        dim, depth, heads = BEIT_CONFIGS[name]
+        self.num_features = dim
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.patch_embed = _ViTPatchEmbed(dim)
+        self.blocks = nn.ModuleList([_BeitBlock(dim, heads, 14, init_values) for _ in range(depth)])
+        self.fc_norm = nn.LayerNorm(dim, eps=1e-6)
+
+    def forward(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
+        for blk in self.blocks:
+            x = blk(x)
+        return self.fc_norm(x[:, 1:].mean(dim=1))

@@ -183,3 +183,13 @@ def test_liwterm_drop_in_key_layout():
     assert list(hip.state_dict().keys()) == golden("alt_models")["liwterm"]["keys"]
     hip.load_state_dict(ora.state_dict(), strict=True)
     assert not any(p.requires_grad for p in LiwTERM(6, 20, image_encoder="vit_tiny_patch16_224").visual.parameters())
+
+
+def test_timm_branch_beit_and_vit_layout():
+    from models.loadImageModelClassifier import loadModels
+    from oracle.altmodels import OracleBeit, OracleViT
+    m, dim = loadModels.loadModelImageEncoder("beitv2_base_patch16_224", 64, "partial")
+    assert dim == 768 and list(m.state_dict().keys()) == list(OracleBeit("beitv2_base_patch16_224").state_dict().keys())
+    assert all(k.startswith("blocks.11.") for k, p in m.named_parameters() if p.requires_grad)
+    m, dim = loadModels.loadModelImageEncoder("vit_small_patch16_224", 64, "frozen_weights")
+    assert dim == 384 and list(m.state_dict().keys()) == list(OracleViT("vit_small_patch16_224").state_dict().keys())
