@@ -189,6 +189,11 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream);
 int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream);
 int mmskin_gelu_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+/* fp32 NHWC depthwise 3x3 convolution (stride 1, pad 1) with its gradients -- ConvPosEnc of timm's DaViT blocks */
+int64_t mmskin_dwconv3_scratch_floats(int N, int H, int W, int C);
+int mmskin_dwconv3_forward(const float* x, const float* w, float* w_stage, float* y, int N, int H, int W, int C, void* stream);
+int mmskin_dwconv3_backward(const float* dy, const float* x, const float* w, float* w_stage, float* scratch, float* dx, float* dw,
+                            int N, int H, int W, int C, void* stream);
 /* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
                              void* stream);

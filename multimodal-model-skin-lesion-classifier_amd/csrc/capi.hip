@@ -367,4 +367,26 @@ int mmskin_stem_backward(const float* dy, const float* x, const float* w, const 
            stem_bwd_op<bf16_t>(dy, x, w, gamma, beta, dw, dgamma, dbeta, N, H, W, eps, workspace, st));
 }
 
+/* fp32 NHWC depthwise 3x3 (stride 1, pad 1) for token-layout models (DaViT's convolutional position encoding):
+ * w is the nn.Conv2d(groups = C) weight [C][1][3][3]; w_stage holds 9*C floats; backward also needs
+ * mmskin_dwconv3_scratch_floats(...) floats of scratch. */
+int64_t mmskin_dwconv3_scratch_floats(int N, int H, int W, int C) { return (int64_t)dwconv3_wgrad_partial_floats(N, H, W, C, 1, 3); }
+int mmskin_dwconv3_forward(const float* x, const float* w, float* w_stage, float* y, int N, int H, int W, int C, void* stream) {
+  ARG_CHECK(x && w && w_stage && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv3_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dw_stage_weights<float>(w, C, C, w_stage, st, 3);
+  if (rc) return rc;
+  return dwconv3_fwd<float>(x, w_stage, N, H, W, C, 1, y, st, 3);
+}
+int mmskin_dwconv3_backward(const float* dy, const float* x, const float* w, float* w_stage, float* scratch, float* dx, float* dw,
+                            int N, int H, int W, int C, void* stream) {
+  ARG_CHECK(dy && x && w && w_stage && scratch && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv3_backward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dw_stage_weights<float>(w, C, C, w_stage, st, 3);
+  if (rc) return rc;
+  if (dx && (rc = dwconv3_dgrad<float>(dy, w_stage, N, H, W, C, 1, dx, st, 3))) return rc;
+  if (dw && (rc = dwconv3_wgrad<float>(dy, x, N, H, W, C, 1, scratch, dw, C, st, 3))) return rc;
+  return MMSKIN_OK;
+}
+
 }  // extern "C"

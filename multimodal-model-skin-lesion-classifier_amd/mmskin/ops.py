@@ -439,6 +439,37 @@ class TokenMeanFn(torch.autograd.Function):
 token_mean = TokenMeanFn.apply
 
 
+class DwConv3Fn(torch.autograd.Function):
+    """Depthwise 3x3 (stride 1, pad 1) on NHWC fp32: x [N, H, W, C], w [C, 1, 3, 3] -> [N, H, W, C]."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_gpu(x, "dwconv3")
+        x, w = _f32c(x), _f32c(w)
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        stage = torch.empty(9 * C, device=x.device, dtype=torch.float32)
+        call("mmskin_dwconv3_forward", ptr(x), ptr(w), ptr(stage), ptr(y), N, H, W, C, stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dy = _f32c(dy)
+        stage = torch.empty(9 * C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(_lib.load().mmskin_dwconv3_scratch_floats(N, H, W, C), device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        call("mmskin_dwconv3_backward", ptr(dy), ptr(x), ptr(w), ptr(stage), ptr(scratch), ptr(dx) if dx is not None else None,
+             ptr(dw) if dw is not None else None, N, H, W, C, stream())
+        return dx, dw
+
+
+dwconv3 = DwConv3Fn.apply
+
+
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

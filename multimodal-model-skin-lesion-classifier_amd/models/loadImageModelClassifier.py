@@ -76,12 +76,15 @@ class loadModels:
                     p.requires_grad = True
             else:
                 loadModels.set_backbone_train_mode(model, backbone_train_mode)
-        elif cnn_model_name.startswith(("beitv2_", "vit_")):
+        elif cnn_model_name.startswith(("beitv2_", "vit_", "davit_")):
             # the reference's generic timm branch (:117-152): create_model(name) + reset_classifier(0), F = num_features,
             # "partial" unfreezes the last block
             if cnn_model_name.startswith("beitv2_"):
                 from hip_beit import HipBeit
                 model = HipBeit(cnn_model_name)
+            elif cnn_model_name.startswith("davit_"):
+                from hip_davit import HipDaVit
+                model = HipDaVit(cnn_model_name)
             else:
                 from hip_vit import HipVisionTransformer
                 model = HipVisionTransformer(cnn_model_name)
@@ -89,7 +92,8 @@ class loadModels:
             if backbone_train_mode == "partial":
                 for p in model.parameters():
                     p.requires_grad = False
-                for p in model.blocks[-1].parameters():
+                last = model.stages[-1] if hasattr(model, "stages") else model.blocks[-1]      # reference :125-131
+                for p in last.parameters():
                     p.requires_grad = True
             else:
                 loadModels.set_backbone_train_mode(model, backbone_train_mode)

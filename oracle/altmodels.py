@@ -260,3 +260,140 @@ class OracleBeit(nn.Module):
         for blk in self.blocks:
             x = blk(x)
         return self.fc_norm(x[:, 1:].mean(dim=1))
+
+
+class _LN2d(nn.LayerNorm):
+    """timm LayerNorm2d: LayerNorm over the channel dim of NCHW."""
+
+    def forward(self, x):
+        return F.layer_norm(x.permute(0, 2, 3, 1), self.normalized_shape, self.weight, self.bias, self.eps).permute(0, 3, 1, 2)
+
+
+class _DvCpe(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
+
+    def forward(self, x):
+        return x + self.proj(x)
+
+
+class _DvWindowAttn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B_, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B_, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        attn = ((q * (C // self.num_heads) ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+        return self.proj((attn @ v).transpose(1, 2).reshape(B_, N, C))
+
+
+class _DvChannelAttn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.groups = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.groups, C // self.groups).permute(2, 0, 3, 1, 4)
+        q = q * N ** -0.5                                   # timm 1.0.x: dynamic_scale=True
+        attn = (q.transpose(-1, -2) @ k).softmax(dim=-1)
+        x = (attn @ v.transpose(-1, -2)).transpose(-1, -2)
+        return self.proj(x.transpose(1, 2).reshape(B, N, C))
+
+
+class _DvBlock(nn.Module):
+    def __init__(self, dim, heads, spatial):
+        super().__init__()
+        self.spatial = spatial
+        self.cpe1 = _DvCpe(dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = _DvWindowAttn(dim, heads) if spatial else _DvChannelAttn(dim, heads)
+        self.cpe2 = _DvCpe(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = _ViTMlp(dim, dim * 4)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        shortcut = self.cpe1(x).flatten(2).transpose(1, 2)
+        h = self.norm1(shortcut)
+        if self.spatial:
+            ws = 7
+            h = h.view(B, H, W, C)
+            pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+            h = F.pad(h, (0, 0, 0, pr, 0, pb))
+            Hp, Wp = H + pb, W + pr
+            win = h.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+            a = self.attn(win).view(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+            h = a[:, :H, :W, :].reshape(B, H * W, C)
+        else:
+            h = self.attn(h)
+        x = shortcut + h
+        x = self.cpe2(x.transpose(1, 2).view(B, C, H, W)).flatten(2).transpose(1, 2)
+        x = x + self.mlp(self.norm2(x))
+        return x.transpose(1, 2).view(B, C, H, W)
+
+
+class _DvStem(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv2d(3, dim, 7, 4, 3)
+        self.norm = _LN2d(dim)
+
+    def forward(self, x):
+        return self.norm(self.conv(x))
+
+
+class _DvDown(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm = _LN2d(cin)
+        self.conv = nn.Conv2d(cin, cout, 2, 2)
+
+    def forward(self, x):
+        return self.conv(self.norm(x))
+
+
+class _DvStage(nn.Module):
+    def __init__(self, cin, cout, depth, heads, downsample):
+        super().__init__()
+        self.downsample = _DvDown(cin, cout) if downsample else nn.Identity()
+        self.blocks = nn.Sequential(*[nn.Sequential(_DvBlock(cout, heads, True), _DvBlock(cout, heads, False)) for _ in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+class _DvHead(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = _LN2d(dim)
+
+
+DAVIT_CONFIGS = {"davit_tiny": ((1, 1, 3, 1), (96, 192, 384, 768), (3, 6, 12, 24))}
+
+
+class OracleDaVit(nn.Module):
+    """timm DaVit (davit_tiny after reset_classifier(0)) restated in timm's NCHW formulation.  PARITY UNPINNED against timm."""
+
+    def __init__(self, name="davit_tiny"):
+        super().__init__()
+        depths, dims, heads = DAVIT_CONFIGS[name.split(".")[0]]
+        self.num_features = dims[-1]
+        self.stem = _DvStem(dims[0])
+        stages, cin = [], dims[0]
+        for i in range(4):
+            stages.append(_DvStage(cin, dims[i], depths[i], heads[i], i > 0))
+            cin = dims[i]
+        self.stages = nn.Sequential(*stages)
+        self.head = _DvHead(dims[-1])
+
+    def forward(self, x):
+        x = self.stages(self.stem(x))
+        return self.head.norm(x.mean(dim=(2, 3), keepdim=True)).flatten(1)

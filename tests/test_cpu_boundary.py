@@ -193,3 +193,15 @@ def test_timm_branch_beit_and_vit_layout():
     assert all(k.startswith("blocks.11.") for k, p in m.named_parameters() if p.requires_grad)
     m, dim = loadModels.loadModelImageEncoder("vit_small_patch16_224", 64, "frozen_weights")
     assert dim == 384 and list(m.state_dict().keys()) == list(OracleViT("vit_small_patch16_224").state_dict().keys())
+
+
+def test_timm_branch_davit_layout():
+    from models.loadImageModelClassifier import loadModels
+    from oracle.altmodels import OracleDaVit
+    m, dim = loadModels.loadModelImageEncoder("davit_tiny.msft_in1k", 64, "partial")
+    assert dim == 768 and list(m.state_dict().keys()) == list(OracleDaVit().state_dict().keys())
+    assert sum(p.numel() for p in m.parameters()) == 27591168                       # timm davit_tiny without its classifier
+    assert all(k.startswith("stages.3.") for k, p in m.named_parameters() if p.requires_grad)
+    import pytest
+    with pytest.raises(ValueError):
+        loadModels.loadModelImageEncoder("mvitv2_small.fb_in1k", 64, "frozen_weights")
