@@ -65,6 +65,13 @@ WORKLOADS = {
                    attention_mecanism="crossattention"),
         "flop_per_image": 3 * 0.78e9,   # torchvision efficientnet_b0: 0.39 GMAC forward
     },
+    "davit-tiny-gfcam": {
+        "metric": "images/sec fwd+bwd, DaViT-tiny+tab-transformer+gfcam",
+        "label": "davit_tiny.msft_in1k + tab-transformer(82 cat + 4 cont) + gfcam, 224x224, train step incl. Adam (fp32 ops)",
+        "kw": dict(cnn_model_name="davit_tiny.msft_in1k", text_model_name="tab-transformer", common_dim=512, vocab_size=86,
+                   attention_mecanism="gfcam"),
+        "flop_per_image": 3 * 9.0e9,   # timm davit_tiny: 4.5 GMAC forward
+    },
     "vgg16-crossattention": {
         "metric": "images/sec fwd+bwd, VGG-16+crossattention bs=256",
         "label": "VGG-16 + one-hot(20) + crossattention, 224x224, train step incl. Adam",
@@ -76,7 +83,7 @@ WORKLOADS = {
 
 
 def make_meta(workload, batch, generator):
-    if workload == "densenet169-metablock":   # 82 categorical codes (cardinality 10) + 4 continuous columns
+    if workload in ("densenet169-metablock", "davit-tiny-gfcam"):   # 82 categorical codes (cardinality 10) + 4 continuous columns
         cat = torch.randint(0, 10, (batch, 82), generator=generator).float()
         return torch.cat([cat, torch.randn(batch, 4, generator=generator)], dim=1)
     return torch.randn(batch, 20, generator=generator)
@@ -203,6 +210,8 @@ def main():
     roofline = None
     if rank == 0 and not args.no_roofline and not args.infer:
         enc = model.image_encoder.features if hasattr(model.image_encoder, "classifier") and hasattr(model.image_encoder.features, "_plans") else model.image_encoder
+        if not hasattr(enc, "_plans"):
+            raise SystemExit("this workload has no plan executor: run with --no-roofline")
         plan = next(iter(enc._plans.values()))
         lib = _lib.load()
         lib.mmskin_backbone_profile_enable(plan.handle, 1)

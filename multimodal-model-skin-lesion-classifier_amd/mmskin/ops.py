@@ -328,7 +328,9 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None):
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
         _dropout_counter[0] += B * H * L * L
         offset = _dropout_counter[0]
-    if mask_add is not None or bias is not None or L * L * 4 > 64 * 1024:
+    # the one-workgroup-per-head kernel keeps L x L scores in LDS and walks the feature dimension serially: long sequences
+    # and long feature dimensions (DaViT's channel attention: feature = tokens) go through the batched-GEMM path
+    if mask_add is not None or bias is not None or L * L * 4 > 64 * 1024 or q.shape[3] > 256:
         return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset, bias)
     if p <= 0.0:
         return AttentionFn.apply(q, k, v, 0.0, 0, 0)

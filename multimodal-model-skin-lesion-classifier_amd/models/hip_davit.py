@@ -188,10 +188,13 @@ class HipDaVit(nn.Module):
         ph, pw = (4 - x.shape[2] % 4) % 4, (4 - x.shape[3] % 4) % 4
         if ph or pw:
             x = torch.nn.functional.pad(x, (0, pw, 0, ph))
-        x = ops.direct_conv2d(x.contiguous(), self.stem.conv.weight, self.stem.conv.bias, 4, 3, False)   # [B, C, H/4, W/4]
-        x = x.permute(0, 2, 3, 1).contiguous()
-        B, H, W, C = x.shape
-        x = _layernorm(self.stem.norm, x.reshape(B * H * W, C)).reshape(B, H, W, C)
+        # 7x7/4 stem conv (pad 3) as a Linear over unfolded 7x7x3 patches (im2col is a data-layout step)
+        B, _, Hi, Wi = x.shape
+        H, W = (Hi + 6 - 7) // 4 + 1, (Wi + 6 - 7) // 4 + 1
+        cols = torch.nn.functional.unfold(x, kernel_size=7, padding=3, stride=4).transpose(1, 2).reshape(B * H * W, 147).contiguous()
+        x = ops.linear(cols, self.stem.conv.weight.flatten(1), self.stem.conv.bias)
+        C = x.shape[1]
+        x = _layernorm(self.stem.norm, x).reshape(B, H, W, C)
         for stage in self.stages:
             if not isinstance(stage.downsample, nn.Identity):
                 ds = stage.downsample
