@@ -3,6 +3,9 @@
 // multimodalIntraInterModal.py:172-412, metablock.py:27-32, gatedResidualBlock.py:12-17,
 // tab_transformer.py:40-60.  Dense contractions run on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32);
 // row reductions (LayerNorm, softmax) are wavefront-shuffle reductions, one 64-lane wave per row.
+#include <stdlib.h>
+#include <string.h>
+
 #include "../../include/mmskin.h"
 #include "common.h"
 #include "conv.h"
@@ -177,6 +180,54 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, float* __rest
 }
 // Linear layers over batch x tokens rows with 64-multiple widths run on the exact-f32 implicit-GEMM conv kernels
 static inline bool linear_big(int M, int K, int N) { return M >= 2048 && K % 64 == 0 && N % 64 == 0; }
+// MMSKIN_LINEAR_DTYPE=bf16: those GEMMs take bf16 operands (fp32 accumulate, fp32 tensors at the boundary): the inputs are
+// converted into library scratch, the bf16 MFMA kernels run, the result is converted back.  Default fp32 (parity mode).
+static inline bool linear_bf16() {
+  static const bool v = [] { const char* e = getenv("MMSKIN_LINEAR_DTYPE"); return e && !strcmp(e, "bf16"); }();
+  return v;
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<uint2*>(out)[i] = make_uint2(f32_to_bf16_bits(v.x) | (f32_to_bf16_bits(v.y) << 16),
+                                                  f32_to_bf16_bits(v.z) | (f32_to_bf16_bits(v.w) << 16));
+  }
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint2 v = reinterpret_cast<const uint2*>(in)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(bf16_bits_to_f32(v.x & 0xffffu), bf16_bits_to_f32(v.x >> 16),
+                                                    bf16_bits_to_f32(v.y & 0xffffu), bf16_bits_to_f32(v.y >> 16));
+  }
+}
+// out[k][n] (bf16) = in[n][k] (fp32)
+__global__ void transpose_f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[i][threadIdx.x] = in[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(int64_t)c * rows + r] = (bf16_t)f32_to_bf16_bits(tile[threadIdx.x][i]);
+  }
+}
+static int cvt_to_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t st) {
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, out, n4);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+static int cvt_to_f32(const bf16_t* in, float* out, int64_t n, hipStream_t st) {
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, out, n4);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
 
 __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -735,6 +786,19 @@ extern "C" {
 int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
                           void* stream) {
   ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+  if (linear_big(M, K, N) && linear_bf16()) {
+    ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+    const size_t xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256), yb = align_up((size_t)M * N * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb + yb));
+    if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
+    int rc;
+    if ((rc = cvt_to_bf16(x, x16, (int64_t)M * K, ST(stream)))) return rc;
+    if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, ST(stream)))) return rc;
+    FwdFuse f; f.bias = b; f.relu = relu != 0;
+    if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, y16, nullptr, nullptr, ST(stream), (b || relu) ? &f : nullptr))) return rc;
+    return cvt_to_f32(y16, y, (int64_t)M * N, ST(stream));
+  }
   if (linear_big(M, K, N)) {   // tokens x hidden GEMMs of the text encoders: the exact-f32 implicit-GEMM kernel as a 1x1 conv
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
     FwdFuse f; f.bias = b; f.relu = relu != 0;
@@ -755,6 +819,29 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     g = dy_scratch;
   }
   int rc;
+  if (linear_big(M, K, N) && linear_bf16()) {
+    ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+    const size_t gb = align_up((size_t)M * N * 2, 256), xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + align_up(conv_wgrad_slab_bytes(s), 256)));
+    if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
+    float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
+    if ((rc = cvt_to_bf16(g, g16, (int64_t)M * N, st))) return rc;
+    if (dx) {
+      ARG_CHECK(w, "linear_backward: w required for dx");
+      hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3(ceil_div(K, 32), ceil_div(N, 32)), dim3(32, 8), 0, st, w, w16, N, K);
+      HIP_CHECK_RET(hipGetLastError());
+      if ((rc = launch_conv_dgrad<bf16_t>(s, g16, w16, t16, (const bf16_t*)nullptr, st))) return rc;   // dx in bf16, then widened
+      if ((rc = cvt_to_f32(t16, dx, (int64_t)M * K, st))) return rc;
+    }
+    if (dw) {
+      ARG_CHECK(x, "linear_backward: x required for dw");
+      if ((rc = cvt_to_bf16(x, t16, (int64_t)M * K, st))) return rc;
+      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, t16, slab, dw, st))) return rc;
+    }
+    if (db && (rc = colsum(g, db, M, N, st))) return rc;
+    return MMSKIN_OK;
+  }
   if (linear_big(M, K, N)) {
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
     const size_t wt_bytes = align_up((size_t)N * K * sizeof(float), 256);

@@ -5,6 +5,8 @@ Tolerances (written per test) are on max|got-want| / rms(want): the exact-f32 MF
 every element to 2^-9 relative, i.e. up to ~1% of the rms for the largest (4-5 sigma) elements, on top of
 the rounded operands.
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -287,3 +289,34 @@ def test_custom_cnn_pieces():
     out = ops.pool_gap(ops.direct_conv2d(x.to(DEV), wd, bd, 2, 1, True), 2)
     out.backward(dy.to(DEV))
     _chk(out, ref); _chk(wd.grad, wr.grad, 1e-4); _chk(bd.grad, br.grad, 1e-4)
+
+
+def test_linear_bf16_operand_mode():
+    """MMSKIN_LINEAR_DTYPE=bf16: Linear layers over batch x tokens rows run on the bf16 MFMA kernels (fp32 accumulate,
+    fp32 tensors at the boundary).  Checked in a fresh process (the mode is read once) against torch on bf16-rounded inputs."""
+    import subprocess, sys
+    code = r'''
+import sys, os
+sys.path[:0] = [%r, %r]
+import torch, torch.nn.functional as F
+from mmskin import ops
+g = torch.Generator().manual_seed(3)
+M, K, N = 4096, 256, 192
+rb = lambda t: t.bfloat16().float()
+x = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) / K ** 0.5); b = torch.randn(N, generator=g)
+dy = rb(torch.randn(M, N, generator=g))
+xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+y_ref = F.linear(xr, wr, br); y_ref.backward(dy)
+xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+y = ops.linear(xd, wd, bd, False); y.backward(dy.cuda())
+def l2(a, r): return float((a.cpu().double() - r.double()).norm() / r.double().norm())
+errs = [l2(y, y_ref), l2(xd.grad, xr.grad), l2(wd.grad, wr.grad), l2(bd.grad, br.grad)]
+print("ERRS", errs)
+assert all(e < 1e-2 for e in errs), errs
+assert errs[0] > 1e-5      # really the bf16 path (outputs rounded to bf16), not the fp32 one
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMSKIN_LINEAR_DTYPE="bf16")
+    r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
