@@ -177,7 +177,8 @@ int mmskin_mdnet_fuse_backward(const float* dpooled, const float* feat, const fl
 int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N, int K, int64_t sam, int64_t sak, int64_t sab,
                int64_t sbn, int64_t sbk, int64_t sbb, int64_t ldc, int64_t scb, void* stream);
 int mmskin_softmax_forward(const float* x, const float* mask_add, const float* bias /* [rows_per_batch][L] or NULL */,
-                           float* y, int64_t rows, int L, int64_t rows_per_batch, float scale, void* stream);
+                           float* y, int64_t rows, int L, int64_t rows_per_batch, float scale,
+                           int causal /* GPT-2: key j <= query i */, void* stream);
 int mmskin_softmax_backward(const float* dy, const float* y, float* dx, int64_t rows, int L, float scale, void* stream);
 /* pieces of the timm transformer blocks (BEiT: LayerScale residuals, mean pooling over patch tokens, bias gradients) */
 int mmskin_colsum(const float* x, float* out, int M, int N, void* stream);
@@ -189,6 +190,8 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream);
 int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream);
 int mmskin_gelu_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int mmskin_gelu_tanh_forward(const float* x, float* y, int64_t n, void* stream);      /* GPT-2 "gelu_new" */
+int mmskin_gelu_tanh_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream);
 /* fp32 NHWC depthwise 3x3 convolution (stride 1, pad 1) with its gradients -- ConvPosEnc of timm's DaViT blocks */
 int64_t mmskin_dwconv3_scratch_floats(int N, int H, int W, int C);
 int mmskin_dwconv3_forward(const float* x, const float* w, float* w_stage, float* y, int N, int H, int W, int C, void* stream);

@@ -713,21 +713,23 @@ __global__ void pool_gap_bwd_kernel(const float* dy, const int32_t* idx, float* 
 // bias (optional): [rows_per_batch][L] added to every batch's scores (per-head relative-position bias of BEiT)
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask_add,
                                                           const float* __restrict__ bias, float* __restrict__ y, int64_t rows,
-                                                          int L, int64_t rows_per_batch, float scale) {
+                                                          int L, int64_t rows_per_batch, float scale, int causal) {
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* xr = x + r * L;
   const float* mk = mask_add ? mask_add + (r / rows_per_batch) * L : nullptr;
   const float* bs = bias ? bias + (r % rows_per_batch) * L : nullptr;
+  const int jend = causal ? (int)(r % L) + 1 : L;      // causal (GPT-2): query i attends keys 0..i (square score matrices)
   float mx = -INFINITY;
-  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f));
+  for (int j = lane; j < jend; j += 64) mx = fmaxf(mx, xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f));
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int j = lane; j < L; j += 64) sum += expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx);
+  for (int j = lane; j < jend; j += 64) sum += expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx);
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
-  for (int j = lane; j < L; j += 64) y[r * L + j] = expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx) * inv;
+  for (int j = lane; j < L; j += 64)
+    y[r * L + j] = j < jend ? expf(xr[j] * scale + (mk ? mk[j] : 0.f) + (bs ? bs[j] : 0.f) - mx) * inv : 0.f;
 }
 // y = x + gamma[c] * b  (LayerScale residual), and its pieces backward
 __global__ void scale_add_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ gamma,
@@ -764,6 +766,19 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int j = lane; j < L; j += 64) dot += dy[r * L + j] * y[r * L + j];
   dot = wave_sum(dot);
   for (int j = lane; j < L; j += 64) dx[r * L + j] = (dy[r * L + j] - dot) * y[r * L + j] * scale;
+}
+// GPT-2's "gelu_new": 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__global__ void gelu_tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  EW_LOOP(n) { const float v = x[i]; y[i] = 0.5f * v * (1.f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v))); }
+}
+__global__ void gelu_tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
+  EW_LOOP(n) {
+    const float v = x[i];
+    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+    const float t = tanhf(u);
+    const float du = 0.7978845608028654f * (1.f + 3.f * 0.044715f * v * v);
+    dx[i] = dy[i] * (0.5f * (1.f + t) + 0.5f * v * (1.f - t * t) * du);
+  }
 }
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n, int64_t nb) {
   EW_LOOP(n) y[i] = a[i] + b[i % nb];   // b broadcasts over the leading dimension when nb < n
@@ -987,10 +1002,10 @@ int mmskin_bmm(const float* a, const float* b, float* c, int batch, int M, int N
   return gemm_f32(a, b, c, nullptr, M, N, K, sam, sak, sbn, sbk, ldc, 0, ST(stream), batch, sab, sbb, scb);
 }
 int mmskin_softmax_forward(const float* x, const float* mask_add, const float* bias, float* y, int64_t rows, int L,
-                           int64_t rows_per_batch, float scale, void* stream) {
+                           int64_t rows_per_batch, float scale, int causal, void* stream) {
   ARG_CHECK(x && y && rows > 0 && L > 0 && rows_per_batch > 0, "softmax_forward: bad argument");
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ST(stream), x, mask_add, bias, y, rows, L,
-                     rows_per_batch, scale);
+                     rows_per_batch, scale, causal);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1026,6 +1041,10 @@ int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, 
   EW_LAUNCH(add_kernel, n, a, b, y, n, nb);
 }
 int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream) { EW_LAUNCH(gelu_fwd_kernel, n, x, y, n); }
+int mmskin_gelu_tanh_forward(const float* x, float* y, int64_t n, void* stream) { EW_LAUNCH(gelu_tanh_fwd_kernel, n, x, y, n); }
+int mmskin_gelu_tanh_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
+  EW_LAUNCH(gelu_tanh_bwd_kernel, n, dy, x, dx, n);
+}
 int mmskin_gelu_backward(const float* dy, const float* x, float* dx, int64_t n, void* stream) {
   EW_LAUNCH(gelu_bwd_kernel, n, dy, x, dx, n);
 }

@@ -77,7 +77,9 @@ _SIGNATURES = {
     "mmskin_attention_forward": (_i, [_P] * 5 + [_i] * 4 + [_f, _u64, _u64, _P]),
     "mmskin_attention_backward": (_i, [_P] * 8 + [_i] * 4 + [_f, _u64, _u64, _P]),
     "mmskin_bmm": (_i, [_P] * 3 + [_i] * 4 + [_i64] * 8 + [_P]),
-    "mmskin_softmax_forward": (_i, [_P] * 4 + [_i64, _i, _i64, _f, _P]),
+    "mmskin_softmax_forward": (_i, [_P] * 4 + [_i64, _i, _i64, _f, _i, _P]),
+    "mmskin_gelu_tanh_forward": (_i, [_P, _P, _i64, _P]),
+    "mmskin_gelu_tanh_backward": (_i, [_P, _P, _P, _i64, _P]),
     "mmskin_colsum": (_i, [_P, _P, _i, _i, _P]),
     "mmskin_dwconv3_scratch_floats": (_i64, [_i, _i, _i, _i]),
     "mmskin_dwconv3_forward": (_i, [_P] * 4 + [_i] * 4 + [_P]),

@@ -265,7 +265,7 @@ class LongAttentionFn(torch.autograd.Function):
     q, k, v [B, H, L, Dh]; mask_add [B, L] additive key mask or None; dropout on the probabilities when drop_p > 0."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask_add, drop_p, seed, offset, bias=None):
+    def forward(ctx, q, k, v, mask_add, drop_p, seed, offset, bias=None, causal=False):
         _need_gpu(q, "attention")
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
         B, H, L, Dh = q.shape
@@ -276,7 +276,7 @@ class LongAttentionFn(torch.autograd.Function):
         m = _f32c(mask_add) if mask_add is not None else None
         bs = _f32c(bias) if bias is not None else None                              # [H, L, L], shared by the batch
         call("mmskin_softmax_forward", ptr(scores), ptr(m) if m is not None else None, ptr(bs) if bs is not None else None,
-             ptr(probs), BH * L, L, H * L, 1.0 / Dh ** 0.5, stream())
+             ptr(probs), BH * L, L, H * L, 1.0 / Dh ** 0.5, int(causal), stream())
         ctx.has_bias = bias is not None
         del scores
         dmask = None
@@ -317,10 +317,10 @@ class LongAttentionFn(torch.autograd.Function):
             dbias = torch.empty((H, L, L), device=q.device, dtype=torch.float32)
             call("mmskin_colsum", ptr(ds), ptr(dbias), B, H * L * L, stream())
             dbias.mul_(Dh ** 0.5)
-        return dq, dk, dv, None, None, None, None, dbias
+        return dq, dk, dv, None, None, None, None, dbias, None
 
 
-def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None):
+def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
     seed = offset = 0
@@ -330,8 +330,8 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None):
         offset = _dropout_counter[0]
     # the one-workgroup-per-head kernel keeps L x L scores in LDS and walks the feature dimension serially: long sequences
     # and long feature dimensions (DaViT's channel attention: feature = tokens) go through the batched-GEMM path
-    if mask_add is not None or bias is not None or L * L * 4 > 64 * 1024 or q.shape[3] > 256:
-        return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset, bias)
+    if mask_add is not None or bias is not None or causal or L * L * 4 > 64 * 1024 or q.shape[3] > 256:
+        return LongAttentionFn.apply(q, k, v, mask_add, p, seed, offset, bias, causal)
     if p <= 0.0:
         return AttentionFn.apply(q, k, v, 0.0, 0, 0)
     return AttentionFn.apply(q, k, v, p, seed, offset)
@@ -492,6 +492,28 @@ class GeluFn(torch.autograd.Function):
 
 
 gelu = GeluFn.apply
+
+
+class GeluTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "gelu_tanh")
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call("mmskin_gelu_tanh_forward", ptr(x), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        call("mmskin_gelu_tanh_backward", ptr(dy), ptr(x), ptr(dx), x.numel(), stream())
+        return dx
+
+
+gelu_tanh = GeluTanhFn.apply
 
 
 class EmbeddingFn(torch.autograd.Function):

@@ -116,8 +116,12 @@ class loadModels:
                 p.requires_grad = train_mode == "unfrozen_weights"
             return model, output_dim, output_dim
         elif text_model_encoder == "gpt2":
-            raise NotImplementedError(
-                "Text encoder 'gpt2' is accepted by the reference but has no MI355X kernels yet (see DESIGN.md, scope table).")
+            from hip_gpt2 import HipGPT2Model
+            model = HipGPT2Model()
+            output_dim = model.config.hidden_size
+            for p in model.parameters():
+                p.requires_grad = train_mode == "unfrozen_weights"
+            return model, output_dim, output_dim
         elif text_model_encoder == "tab-transformer":
             categorical_cardinalities = [10] * 82
             output_dim = 85

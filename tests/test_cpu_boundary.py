@@ -174,6 +174,17 @@ def test_bert_key_layout_matches_transformers():
     hip.load_state_dict(hf.state_dict(), strict=True)
 
 
+def test_gpt2_key_layout_matches_transformers():
+    transformers = __import__("pytest").importorskip("transformers")
+    from models.hip_gpt2 import HipGPT2Model
+    cfg = dict(vocab_size=50, n_positions=16, n_embd=32, n_layer=2, n_head=2)
+    hf = transformers.GPT2Model(transformers.GPT2Config(**cfg))
+    hip = HipGPT2Model(**cfg)
+    assert {k: tuple(v.shape) for k, v in hip.state_dict().items()} == {k: tuple(v.shape) for k, v in hf.state_dict().items()}
+    hip.load_state_dict(hf.state_dict(), strict=True)
+    assert hip.config.hidden_size == 32
+
+
 def test_liwterm_drop_in_key_layout():
     from helpers import golden
     from models.liwtermModel import LiwTERM

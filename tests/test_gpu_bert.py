@@ -72,5 +72,37 @@ def test_bert_factory_and_multimodal_wiring():
     with torch.no_grad():
         out = model(input_ids=ids, attention_mask=torch.ones_like(ids)).last_hidden_state
     assert out.shape == (2, 512, 768) and torch.isfinite(out).all()
-    with pytest.raises(NotImplementedError):
-        loadModels.loadTextModelEncoder("gpt2")
+    g2, d1, _ = loadModels.loadTextModelEncoder("gpt2", "unfrozen_weights")
+    assert d1 == 768 and sum(p.numel() for p in g2.parameters()) == 124439808 and all(p.requires_grad for p in g2.parameters())
+
+
+def test_gpt2_matches_transformers():
+    """GPT-2 (HF Conv1D layout, causal attention + padding mask, gelu_new) vs transformers' GPT2Model on CPU."""
+    from models.hip_gpt2 import HipGPT2Model
+    cfg = dict(vocab_size=120, n_positions=192, n_embd=64, n_layer=2, n_head=4)
+    hf = transformers.GPT2Model(transformers.GPT2Config(**cfg, bos_token_id=0, eos_token_id=0))
+    det_init_(hf)
+    hip = HipGPT2Model(**cfg)
+    hip.load_state_dict(hf.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    g = torch.Generator().manual_seed(7)
+    B, L = 16, 160
+    ids = torch.randint(1, 120, (B, L), generator=g)
+    mask = torch.ones(B, L, dtype=torch.long)
+    mask[2, 100:] = 0
+    w = torch.randn(B, L, 64, generator=g)
+    res = {}
+    for name, m, dev in (("hf", hf, "cpu"), ("hip", hip, DEV)):
+        m.train(); disable_dropout(m)
+        for mod in m.modules():
+            for attr in ("attn_dropout", "resid_dropout", "dropout", "drop"):
+                d = getattr(mod, attr, None)
+                if isinstance(d, torch.nn.Dropout):
+                    d.p = 0.0
+        out = m(input_ids=ids.to(dev), attention_mask=mask.to(dev)).last_hidden_state
+        (out * w.to(dev)).sum().backward()
+        res[name] = (out.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None})
+    assert rel_err(res["hip"][0], res["hf"][0]) < 2e-4
+    assert set(res["hip"][1]) == set(res["hf"][1])
+    bad = {k: rel_err(res["hip"][1][k], v) for k, v in res["hf"][1].items() if rel_err(res["hip"][1][k], v) > 2e-3}
+    assert not bad, bad
