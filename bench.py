@@ -177,13 +177,24 @@ def main():
         with torch.no_grad():
             return model(image, meta).sum()
 
+    # gradient all-reduce queued per encoder segment from inside backward (mmskin/dp.py); MMSKIN_DP_OVERLAP=0: one
+    # all-reduce after backward
+    sync = None
+    if world > 1 and not args.infer and os.environ.get("MMSKIN_DP_OVERLAP", "1") != "0":
+        try:
+            sync = dp.OverlappedGradSync(model, world)
+        except ValueError:
+            sync = None
+
     def step():
         if args.infer:
             return infer_step()
         opt.zero_grad(set_to_none=True)
         loss = crit(model(image, meta), label)
         loss.backward()
-        if world > 1:
+        if sync is not None:
+            sync.finish()
+        elif world > 1:
             dp.allreduce_gradients(model, world)
         opt.step()
         return loss
@@ -216,8 +227,13 @@ def main():
         lib = _lib.load()
         lib.mmskin_backbone_profile_enable(plan.handle, 1)
         nprof = 3
-        for _ in range(nprof):
-            step()
+        if sync is not None:
+            sync.detach()
+        for _ in range(nprof):      # rank 0 only: forward + backward WITHOUT any collective (the other ranks wait at the barrier below)
+            for prm in model.parameters():
+                prm.grad = None
+            crit(model(image, meta), label).backward()
+        torch.cuda.synchronize()
         ms, fl, by = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)()
         ln = (ctypes.c_int64 * 7)()
         _lib.check(lib.mmskin_backbone_profile_read(plan.handle, ms, fl, by, ln))

@@ -78,6 +78,14 @@ int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value);
 /* per-step device pointers: key "sd_mask" (EfficientNet plans) = fp32 [n_residual_blocks][batch] keep/scale factors of
  * torchvision's StochasticDepth(p, "row") for this training step (0 or 1/(1-p)); NULL disables stochastic depth */
 int mmskin_backbone_set_pointer(mmskin_backbone_t h, const char* key, const void* device_ptr);
+/* Gradient segments of the flat gradient arena, in the order backward completes them (ResNet: layer4, layer3,
+ * layer2, layer1 + stem).  `wait_grad_segment` makes `stream` wait (hipStreamWaitEvent) until segment `index` of the
+ * most recently enqueued backward is complete, so a data-parallel caller can all-reduce finished ranges under the rest
+ * of backward.  Build-side addition (the reference is single-GPU, train_pad_20.py:509).  Plans that report
+ * 0 segments are reduced as one range after backward. */
+int mmskin_backbone_num_grad_segments(mmskin_backbone_t h, int* count);
+int mmskin_backbone_grad_segment(mmskin_backbone_t h, int index, int64_t* offset, int64_t* numel);
+int mmskin_backbone_wait_grad_segment(mmskin_backbone_t h, int index, void* stream);
 int mmskin_backbone_last_conv_shape(mmskin_backbone_t h, int* C, int* OH, int* OW);
 int mmskin_backbone_last_conv_export(mmskin_backbone_t h, const void* workspace, float* x_nchw, void* stream);
 int mmskin_backbone_last_conv_grad(mmskin_backbone_t h, const float* dfeatures, const void* workspace, float* dx_nchw,

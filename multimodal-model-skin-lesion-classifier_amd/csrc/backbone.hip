@@ -29,6 +29,7 @@ struct Block {
   size_t mask_off = 0;   // 1-bit ReLU mask of the block output (one byte per 16-byte chunk)
   size_t in_off;   // block input activation (bytes)
   int in_C, in_H, in_W;
+  int seg_done = -1;   // gradient segment that is complete once this block's backward has been enqueued
 };
 
 struct Plan : PlanBase {
@@ -81,6 +82,7 @@ int build_plan(Plan& p) {
   p.PH = (p.OH0 + 2 - 3) / 2 + 1; p.PW = (p.OW0 + 2 - 3) / 2 + 1;
   int cin = 64, h = p.PH, w = p.PW;
   const int widths[4] = {64, 128, 256, 512};
+  std::vector<int64_t> seg_starts;   // first parameter of layer2, layer3, layer4
   for (int li = 0; li < 4; ++li) {
     for (int b = 0; b < depths[li]; ++b) {
       const int stride = (b == 0 && li > 0) ? 2 : 1;
@@ -100,6 +102,10 @@ int build_plan(Plan& p) {
       }
       if (stride != 1 || cin != cout)
         blk.ds = add_unit(p, base + ".downsample.0", base + ".downsample.1", {p.N, h, w, cin, cout, 1, 1, stride, 0});
+      if (b == 0 && li > 0) {   // layerN's parameters start here: everything from this offset on completes first in backward
+        blk.seg_done = 3 - li;
+        seg_starts.push_back(p.units[blk.units[0]].w_off);
+      }
       p.blocks.push_back(blk);
       cin = cout;
       h = (h + 2 - 3) / stride + 1;
@@ -107,6 +113,18 @@ int build_plan(Plan& p) {
     }
   }
   p.feat_dim = cin;
+  {   // gradient segments in backward completion order: layer4, layer3, layer2, layer1 + stem
+    int64_t end = p.param_numel;
+    for (int i = 2; i >= 0; --i) {
+      PlanBase::GradSegment g;
+      g.offset = seg_starts[i]; g.numel = end - seg_starts[i];
+      p.segments.push_back(g);
+      end = seg_starts[i];
+    }
+    PlanBase::GradSegment g;
+    g.offset = 0; g.numel = end;
+    p.segments.push_back(g);
+  }
 
   // ---- staged weights + stage table
   std::vector<StageDesc> table;
@@ -490,6 +508,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
       }
     }
     T* t = g; g = gin; gin = t;
+    if (b.seg_done >= 0 && (rc = p.segment_done(b.seg_done, st, use_side))) return rc;
   }
 
   // join: the stem reuses the scratch buffers and the slab the side stream has been working on
@@ -519,7 +538,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   PROF(K_WGRAD, conv_flops(u0.s), 0.0,
        launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),
                                  slab, dwv, st));
-  return stem_wgrad_unpack(dwv, grads + u0.w_off, st);
+  if ((rc = stem_wgrad_unpack(dwv, grads + u0.w_off, st))) return rc;
+  return p.segment_done((int)p.segments.size() - 1, st, false);
 }
 
 int Plan::forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
@@ -687,6 +707,25 @@ int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value) 
   if (!strcmp(key, "keep_raw_eval")) { h->plan->keep_raw_eval = value != 0; return MMSKIN_OK; }
   mmskin_set_error("backbone_set_option: unknown option '%s'", key);
   return MMSKIN_ERR_ARG;
+}
+int mmskin_backbone_num_grad_segments(mmskin_backbone_t h, int* count) {
+  ARG_CHECK(h && count, "backbone_num_grad_segments: null argument");
+  *count = (int)h->plan->segments.size();   // 0: this plan reports no segments (all-reduce the arena after backward)
+  return MMSKIN_OK;
+}
+int mmskin_backbone_grad_segment(mmskin_backbone_t h, int index, int64_t* offset, int64_t* numel) {
+  ARG_CHECK(h && offset && numel, "backbone_grad_segment: null argument");
+  ARG_CHECK(index >= 0 && index < (int)h->plan->segments.size(), "backbone_grad_segment: index %d", index);
+  *offset = h->plan->segments[index].offset;
+  *numel = h->plan->segments[index].numel;
+  return MMSKIN_OK;
+}
+int mmskin_backbone_wait_grad_segment(mmskin_backbone_t h, int index, void* stream) {
+  ARG_CHECK(h, "backbone_wait_grad_segment: null argument");
+  ARG_CHECK(index >= 0 && index < (int)h->plan->segments.size(), "backbone_wait_grad_segment: index %d", index);
+  int rc = h->plan->segment_wait(index, (hipStream_t)stream);
+  if (rc == MMSKIN_ERR_ARG) mmskin_set_error("backbone_wait_grad_segment: no backward has been enqueued on this plan yet");
+  return rc;
 }
 int mmskin_backbone_set_pointer(mmskin_backbone_t h, const char* key, const void* device_ptr) {
   ARG_CHECK(h && key, "backbone_set_pointer: null argument");

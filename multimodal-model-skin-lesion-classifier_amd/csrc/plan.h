@@ -87,8 +87,38 @@ struct PlanBase {
   size_t ws_bytes = 0;
   size_t esz() const { return dtype == 1 ? 2 : 4; }
 
+  // Gradient segments: contiguous ranges of the flat gradient arena in the order backward COMPLETES them,
+  // each with an event pair (main stream: BN gamma/beta gradients; side stream: weight gradients), so the caller can
+  // start the data-parallel all-reduce of a finished range while the rest of backward is still running.
+  struct GradSegment {
+    int64_t offset = 0, numel = 0;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool side_valid = false;
+  };
+  std::vector<GradSegment> segments;
+  int segment_done(int i, hipStream_t st, bool use_side) {   // called by backward once segment i is fully enqueued
+    GradSegment& g = segments[i];
+    if (!g.ev_main) {
+      HIP_CHECK_RET(hipEventCreateWithFlags(&g.ev_main, hipEventDisableTiming));
+      HIP_CHECK_RET(hipEventCreateWithFlags(&g.ev_side, hipEventDisableTiming));
+    }
+    HIP_CHECK_RET(hipEventRecord(g.ev_main, st));
+    g.side_valid = use_side;
+    if (use_side) HIP_CHECK_RET(hipEventRecord(g.ev_side, side.s));
+    return MMSKIN_OK;
+  }
+  int segment_wait(int i, hipStream_t waiter) {
+    GradSegment& g = segments[i];
+    if (!g.ev_main) return MMSKIN_ERR_ARG;   // no backward has run yet
+    HIP_CHECK_RET(hipStreamWaitEvent(waiter, g.ev_main, 0));
+    if (g.side_valid) HIP_CHECK_RET(hipStreamWaitEvent(waiter, g.ev_side, 0));
+    return MMSKIN_OK;
+  }
+
   virtual ~PlanBase() {
     if (table_dev) (void)hipFree(table_dev);
+    for (GradSegment& g : segments)
+      if (g.ev_main) { (void)hipEventDestroy(g.ev_main); (void)hipEventDestroy(g.ev_side); }
     side.destroy();
   }
   // image: fp32 NCHW, or (norm6 != nullptr) uint8 NHWC normalised on the fly with the 6 host floats mean rgb | std rgb

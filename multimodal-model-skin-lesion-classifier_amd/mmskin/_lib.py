@@ -36,6 +36,9 @@ _SIGNATURES = {
     "mmskin_backbone_feature_hw": (_i, [_P, _P, _P]),
     "mmskin_backbone_set_option": (_i, [_P, ctypes.c_char_p, _i]),
     "mmskin_backbone_set_pointer": (_i, [_P, ctypes.c_char_p, _P]),
+    "mmskin_backbone_num_grad_segments": (_i, [_P, ctypes.POINTER(ctypes.c_int)]),
+    "mmskin_backbone_grad_segment": (_i, [_P, _i, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "mmskin_backbone_wait_grad_segment": (_i, [_P, _i, _P]),
     "mmskin_backbone_last_conv_shape": (_i, [_P, _P, _P, _P]),
     "mmskin_backbone_last_conv_export": (_i, [_P, _P, _P, _P]),
     "mmskin_backbone_last_conv_grad": (_i, [_P, _P, _P, _P, _P]),

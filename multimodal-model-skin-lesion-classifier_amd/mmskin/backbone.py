@@ -69,6 +69,21 @@ class _Plan:
         call("mmskin_backbone_last_conv_shape", self.handle, ctypes.byref(c), ctypes.byref(oh), ctypes.byref(ow))
         return c.value, oh.value, ow.value
 
+    def grad_segments(self):
+        """(offset, numel) ranges of the flat gradient arena in the order backward completes them ([] = unsegmented)."""
+        n = ctypes.c_int()
+        call("mmskin_backbone_num_grad_segments", self.handle, ctypes.byref(n))
+        out = []
+        for i in range(n.value):
+            off, numel = ctypes.c_int64(), ctypes.c_int64()
+            call("mmskin_backbone_grad_segment", self.handle, i, ctypes.byref(off), ctypes.byref(numel))
+            out.append((off.value, numel.value))
+        return out
+
+    def wait_grad_segment(self, index, torch_stream):
+        """Make `torch_stream` wait until segment `index` of the backward enqueued last is complete."""
+        call("mmskin_backbone_wait_grad_segment", self.handle, index, ctypes.c_void_p(torch_stream.cuda_stream))
+
     def tensor_table(self, kind):
         lib = _lib.load()
         out = []
@@ -123,9 +138,16 @@ class _BackboneFn(torch.autograd.Function):
             raise _lib.MMSkinError("image_encoder backward needs a training-mode forward (batch-stat BN)")
         dfeat = dfeat.float().contiguous()
         grads = torch.empty(plan.param_numel, device=dfeat.device, dtype=torch.float32)
+        # data-parallel hook (mmskin/dp.py OverlappedGradSync): told before and after the backward launches are enqueued
+        sync = getattr(module, "_grad_sync", None)
+        fresh = all(p.grad is None for p in module.parameters())   # no accumulation: .grad will alias `grads`
+        if sync is not None:
+            sync.before_encoder_backward()
         call("mmskin_backbone_backward", plan.handle, ptr(dfeat), ptr(module._flat_p), ptr(plan.workspace), ptr(grads),
              stream())
         module.last_flat_grad = grads
+        if sync is not None and fresh and all(ctx.needs_input_grad[3:]):
+            sync.after_encoder_backward(plan, grads)
         # Hand every parameter its gradient as a VIEW of the flat buffer (what DDP calls
         # gradient_as_bucket_view): no per-parameter copy, and the data-parallel all-reduce can run on
         # the one flat buffer.  Autograd itself gets None for these inputs.

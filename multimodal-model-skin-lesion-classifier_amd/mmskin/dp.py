@@ -9,6 +9,13 @@ fusion branch keep grad None on every rank, exactly as on one GPU).
 Buckets: the image encoder's gradients already live in one flat fp32 buffer (the backward C-ABI call
 writes them there and the parameters' .grad are views into it), so that buffer is all-reduced in place
 without any flatten/unflatten copies; the head's gradients are flattened into a second small bucket.
+
+Overlap (`OverlappedGradSync`): the fusion head is last in forward, so its gradients are complete when
+autograd reaches the image encoder; its bucket is launched then.  The encoder's backward is ONE C call
+that enqueues ~300 kernels and returns; the plan records an event pair per gradient segment (ResNet:
+layer4, layer3, layer2, layer1 + stem; `mmskin_backbone_wait_grad_segment`), so right after that call
+returns one all-reduce per segment is queued behind its events and runs on RCCL's stream under the rest
+of backward: layer4's 60 MB start after ~25 % of the encoder's backward.  Only the last 0.9 MB segment is exposed.
 """
 import torch
 import torch.distributed as dist
@@ -53,6 +60,107 @@ def allreduce_gradients(model, world_size=None, group=None):
             g.copy_(r)
         nbytes += bucket.numel() * 4
     return nbytes
+
+
+class OverlappedGradSync:
+    """Gradient averaging overlapped with the image encoder's backward.
+
+        sync = OverlappedGradSync(model)        # once, after the process group exists
+        loss.backward()                          # all-reduces are queued from inside the encoder's backward
+        sync.finish()                            # wait + average; falls back to allreduce_gradients() when nothing was queued
+
+    `finish()` leaves every parameter's .grad equal to what `allreduce_gradients` produces (tests/test_dp.py)."""
+
+    def __init__(self, model, world_size=None, group=None, force=False):
+        self.model = model
+        self.group = group
+        self.world_size = world_size or dist.get_world_size(group)
+        self.active = self.world_size > 1 or force      # force: exercise the queueing on a single-rank group (tests)
+        enc = getattr(model, "image_encoder", None)
+        self.enc = enc if hasattr(enc, "last_flat_grad") else getattr(enc, "features", None)
+        if self.enc is None or not hasattr(self.enc, "last_flat_grad"):
+            raise ValueError("OverlappedGradSync needs a plan-executed image encoder (flat gradient arena)")
+        self.enc._grad_sync = self
+        self._enc_ids = {id(p) for p in self.enc.parameters()}
+        self._streams = []
+        self._reset()
+
+    def _reset(self):
+        self._works = []
+        self._flat = None
+        self._head = None        # (bucket, grads, versions, work)
+
+    def detach(self):
+        self.enc._grad_sync = None
+
+    # ---- called from _BackboneFn.backward (mmskin/backbone.py)
+    @torch.no_grad()
+    def before_encoder_backward(self):
+        self._reset()
+        if not self.active:
+            return
+        ready = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in self._enc_ids]
+        if ready:
+            bucket = _flatten_dense_tensors(ready)
+            work = dist.all_reduce(bucket, group=self.group, async_op=True)
+            self._head = (bucket, ready, [g._version for g in ready], work)
+
+    @torch.no_grad()
+    def after_encoder_backward(self, plan, flat):
+        if not self.active:
+            return
+        segs = plan.grad_segments()
+        if not segs:
+            return
+        on_gpu = flat.is_cuda
+        while on_gpu and len(self._streams) < len(segs):
+            self._streams.append(torch.cuda.Stream(device=flat.device))
+        for i, (off, numel) in enumerate(segs):
+            view = flat[off:off + numel]
+            if on_gpu:
+                s = self._streams[i]
+                with torch.cuda.stream(s):
+                    plan.wait_grad_segment(i, s)      # s waits for the segment's events only, not for the rest of backward
+                    self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+            else:
+                self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
+        self._flat = flat
+
+    # ---- called by the training loop after loss.backward()
+    @torch.no_grad()
+    def finish(self):
+        if not self.active:
+            self._reset()
+            return 0
+        nbytes = 0
+        done_ids = set()
+        if self._flat is not None and self.enc.last_flat_grad is self._flat:
+            for w in self._works:
+                w.wait()
+            self._flat.div_(self.world_size)
+            done_ids |= self._enc_ids
+            nbytes += self._flat.numel() * 4
+        if self._head is not None:
+            bucket, grads, versions, work = self._head
+            work.wait()
+            bucket.div_(self.world_size)
+            live = {id(p.grad): p for p in self.model.parameters() if p.grad is not None}
+            for g, v, r in zip(grads, versions, _unflatten_dense_tensors(bucket, grads)):
+                p = live.get(id(g))
+                if p is not None and g._version == v:    # untouched since it was bucketed: take the averaged value
+                    g.copy_(r)
+                    done_ids.add(id(p))
+            nbytes += bucket.numel() * 4
+        rest = [p.grad for p in self.model.parameters() if p.grad is not None and id(p) not in done_ids]
+        if rest:                                          # anything the overlapped path did not cover
+            bucket = _flatten_dense_tensors(rest)
+            dist.all_reduce(bucket, group=self.group)
+            bucket.div_(self.world_size)
+            for g, r in zip(rest, _unflatten_dense_tensors(bucket, rest)):
+                g.copy_(r)
+            nbytes += bucket.numel() * 4
+        self._reset()
+        return nbytes
 
 
 def shard_indices(n, rank, world_size, epoch_seed=0):
