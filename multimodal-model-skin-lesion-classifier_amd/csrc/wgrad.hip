@@ -269,8 +269,52 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+// float4 variants of the slab reduction (the slabs are ~64 MB per layer: 3 GB per ResNet-50 step).
+// Stage 1: slab[nsplit][total] -> part[G][total]; a thread owns ONE float4 column and walks its group's rows with four
+// independent accumulators -- no LDS, no barrier (the generic partial_reduce gave a thread 1-2 rows and a barrier).
+__global__ __launch_bounds__(256) void wgrad_slab_group_kernel(const float4* __restrict__ slab, float4* __restrict__ part,
+                                                               int nsplit, int total4, int per) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= total4) return;
+  const int r0 = blockIdx.y * per, r1 = min(nsplit, r0 + per);
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  const float4* src = slab + (size_t)r0 * total4 + c;
+  int r = r0;
+#define ACC4(a, u) a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+  for (; r + 3 < r1; r += 4, src += (size_t)4 * total4) {
+    const float4 u0 = src[0], u1 = src[total4], u2 = src[(size_t)2 * total4], u3 = src[(size_t)3 * total4];
+    ACC4(a0, u0) ACC4(a1, u1) ACC4(a2, u2) ACC4(a3, u3)
+  }
+  for (; r < r1; ++r, src += total4) { const float4 u = src[0]; ACC4(a0, u) }
+  part[(size_t)blockIdx.y * total4 + c] =
+      make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+}
+// Final stage: sum nsplit slabs, 4 consecutive k (= 4 consecutive channels of one tap, C % 4 == 0) per thread, scatter to OIHW
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                            int Cout, int C, int ntaps, int Coutv, int Cv) {
+  const int Ktot = C * ntaps;
+  const int total4 = Cout * (Ktot / 4);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  const float4* src = slab + i;
+  int k = 0;
+  for (; k + 1 < nsplit; k += 2, src += (size_t)2 * total4) { const float4 u0 = src[0], u1 = src[total4]; ACC4(a0, u0) ACC4(a1, u1) }
+  if (k < nsplit) { const float4 u = src[0]; ACC4(a0, u) }
+#undef ACC4
+  const float v[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+  const int e = i * 4;
+  const int cout = e / Ktot, kk = e - cout * Ktot;
+  const int tap = kk / C, c = kk - tap * C;
+  if (cout >= Coutv) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c + j < Cv) dw[((size_t)cout * Cv + c + j) * ntaps + tap] = v[j];
+}
+
 // ------------------------------------------------------------------------------------------ host
-static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps) {
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps, int ntaps = 1) {
   BO = (Cout % 128 == 0) ? 128 : 64;
   BKK = (Ktot % 128 == 0) ? 128 : 64;
   // 256-wide cout tiles halve the re-reads of the gathered-input operand (env knob for A/B timing)
@@ -278,10 +322,16 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
   if (bo256 && Cout % 256 == 0 && BKK == 128) BO = 256;
   MS *= (BO == 256) ? 1 : ((BO + BKK == 128) ? 4 : 2);   // rows per stage (MSF of the kernel)
   int tiles = (Cout / BO) * (Ktot / BKK);
-  // workgroups to aim for; swept 512..1536 on MI355X (1024 best).  An LDS-DMA staging variant of this
-  // kernel was measured too and was 10 % slower than the register-staged loop kept here.
-  static const int target = [] { const char* v = getenv("MMSKIN_WGRAD_BLOCKS"); return v ? atoi(v) : 1024; }();
-  int want = ceil_div(target, tiles);
+  // workgroups to aim for (never exceeded: one extra workgroup costs a whole extra round of 2 x 256 resident slots).
+  // Per-layer sweep on MI355X, isolated and inside the training step (scripts/wgrad_sweep.sh): 1x1 layers and 3x3
+  // layers with >= 64 output tiles are fastest with ONE round (<= 512), the other 3x3 layers with two (<= 1024).
+  // An LDS-DMA staging variant of this kernel was measured too and was 10 % slower than the register-staged loop kept here.
+  static const int target_all = env_int("MMSKIN_WGRAD_BLOCKS", 1024);
+  static const int t1 = env_int("MMSKIN_WGRAD_B1", target_all < 512 ? target_all : 512), t3 = env_int("MMSKIN_WGRAD_B3", target_all),
+                   t3big = env_int("MMSKIN_WGRAD_B3BIG", t1);
+  static const int use_floor = env_int("MMSKIN_WGRAD_FLOOR", 1);
+  const int target = ntaps == 1 ? t1 : (tiles >= 64 ? t3big : t3);
+  int want = use_floor ? (target / tiles > 0 ? target / tiles : 1) : ceil_div(target, tiles);
   int max_split = M / (MS * 4) > 0 ? M / (MS * 4) : 1;
   nsplit = want < max_split ? want : max_split;
   if (nsplit < 1) nsplit = 1;
@@ -291,7 +341,6 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
 
 #define WG_DIRECT_SPLITS 32   // more splits than this are pre-reduced to WG_GROUPS partial slabs first
 #define WG_GROUPS 64        // upper bound; small outputs use more groups so the first stage still fills the chip
-static inline int wg_groups(size_t total) { return total < 32768 ? 64 : (total < 131072 ? 32 : 16); }
 
 template <typename T>
 static size_t slab_bytes(int M, int Cout, int Ktot) {
@@ -330,7 +379,7 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   ARG_CHECK(a.C % DT<T>::EPC == 0, "wgrad: C=%d", a.C);
   ARG_CHECK(a.OW <= 240 && a.OH <= 240, "wgrad: output %dx%d too large for the 16-bit reciprocal pixel stepping", a.OH, a.OW);
   int BO, BKK;
-  wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split);
+  wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split, a.ntaps);
   { const char* v = getenv("MMSKIN_WGRAD_ABLATE"); a.ablate = v ? atoi(v) : 0; }
   int rc;
   if (BO == 256) rc = launch_wg<T, 256, 128, 1>(a, st);
@@ -340,21 +389,34 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   else rc = launch_wg<T, 64, 64, 4>(a, st);
   if (rc) return rc;
   size_t total = (size_t)a.Cout * a.Ktot;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 65536) blocks = 65536;
+  const int total4 = (int)(total / 4);
   const float* src = a.slab;
   int nsrc = a.nsplit;
-  if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction
+  if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction to G <= WG_GROUPS partial slabs
     float* slab2 = a.slab + (size_t)a.nsplit * total;
-    int G = wg_groups(total);
-    if (G > a.nsplit / 2) G = a.nsplit / 2;
-    if ((rc = partial_reduce<float>(a.slab, nullptr, a.nsplit, (int)total, G, slab2, st))) return rc;
+    // >= 256k threads where the output allows it, <= 32 rows per thread, at least 2 rows per group
+    int G = ceil_div(262144, total4);
+    const int g_lo = ceil_div(a.nsplit, 32), g_hi = a.nsplit / 2 < WG_GROUPS ? a.nsplit / 2 : WG_GROUPS;
+    if (G < g_lo) G = g_lo;
+    if (G > g_hi) G = g_hi;
+    const int per = ceil_div(a.nsplit, G);
+    G = ceil_div(a.nsplit, per);
+    hipLaunchKernelGGL(wgrad_slab_group_kernel, dim3(ceil_div(total4, 256), G), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(a.slab), reinterpret_cast<float4*>(slab2), a.nsplit, total4, per);
+    HIP_CHECK_RET(hipGetLastError());
     src = slab2;
     nsrc = G;
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout,
-                     C_for_layout, ntaps_for_layout, cout_valid > 0 ? cout_valid : a.Cout,
-                     cin_valid > 0 ? cin_valid : C_for_layout);
+  const int coutv = cout_valid > 0 ? cout_valid : a.Cout, cv = cin_valid > 0 ? cin_valid : C_for_layout;
+  if (C_for_layout % 4 == 0) {
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                       dw, nsrc, a.Cout, C_for_layout, ntaps_for_layout, coutv, cv);
+  } else {
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout, C_for_layout,
+                       ntaps_for_layout, coutv, cv);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
