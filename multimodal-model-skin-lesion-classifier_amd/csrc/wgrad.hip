@@ -343,18 +343,18 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
 #define WG_GROUPS 64        // upper bound; small outputs use more groups so the first stage still fills the chip
 
 template <typename T>
-static size_t slab_bytes(int M, int Cout, int Ktot) {
+static size_t slab_bytes(int M, int Cout, int Ktot, int ntaps) {
   int BO, BKK, ns, mps;
-  wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps);
+  wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps, ntaps);
   return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * Cout * Ktot * sizeof(float);
 }
 size_t conv_wgrad_slab_bytes(const ConvShape& s) {
   int M = s.N * s.OH() * s.OW(), K = s.kh * s.kw * s.Cin;
-  size_t a = slab_bytes<float>(M, s.Cout, K), b = slab_bytes<bf16_t>(M, s.Cout, K);
+  size_t a = slab_bytes<float>(M, s.Cout, K, s.kh * s.kw), b = slab_bytes<bf16_t>(M, s.Cout, K, s.kh * s.kw);
   return a > b ? a : b;
 }
 size_t stem_wgrad_slab_bytes(int N, int OH, int OW) {
-  size_t a = slab_bytes<float>(N * OH * OW, 64, 256), b = slab_bytes<bf16_t>(N * OH * OW, 64, 256);
+  size_t a = slab_bytes<float>(N * OH * OW, 64, 256, 8), b = slab_bytes<bf16_t>(N * OH * OW, 64, 256, 8);   // 8 virtual taps
   return a > b ? a : b;
 }
 
@@ -455,7 +455,7 @@ int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout,
 }
 
 size_t vgg_first_wgrad_slab_bytes(int N, int H, int W) {
-  size_t a = slab_bytes<float>(N * H * W, 64, 128), b = slab_bytes<bf16_t>(N * H * W, 64, 128);
+  size_t a = slab_bytes<float>(N * H * W, 64, 128, 4), b = slab_bytes<bf16_t>(N * H * W, 64, 128, 4);   // 4 virtual taps
   return a > b ? a : b;
 }
 template <typename T>
