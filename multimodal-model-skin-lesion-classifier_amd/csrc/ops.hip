@@ -566,60 +566,64 @@ int stem_pack_u8(const uint8_t* img_nhwc, int N, int H, int W, int Hp, int Wp, c
   return MMSKIN_OK;
 }
 
+// grid (ceil(PW*CPR / 256), PH, N): the pooled row and the image come from the block index, so a thread needs one 32-bit
+// division (64-bit div/mod chains per chunk made these stem kernels instruction-bound at ~2 TB/s)
 template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void stem_bn_relu_pool_kernel(const T* __restrict__ x,
-                                                                    const float* __restrict__ scale,
-                                                                    const float* __restrict__ shift, int N, int H,
-                                                                    int W, int C, int PH, int PW,
-                                                                    T* __restrict__ y, uint8_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void stem_bn_relu_pool_kernel(const T* __restrict__ x,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int N, int H,
+                                                                int W, int C, int PH, int PW,
+                                                                T* __restrict__ y, uint8_t* __restrict__ idx) {
   constexpr int EPC = DT<T>::EPC;
-  const int CPR = C / EPC;
-  const size_t total = (size_t)N * PH * PW * CPR;
-  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
-    int cj = (int)(i % CPR);
-    size_t t = i / CPR;
-    int pw = (int)(t % PW); t /= PW;
-    int ph = (int)(t % PH);
-    int n = (int)(t / PH);
-    const int c0 = cj * EPC;
-    float best[EPC];
-    int bi[EPC];
+  const unsigned CPR = C / EPC;
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= (unsigned)PW * CPR) return;
+  const int pw = (int)(t / CPR), cj = (int)(t - (unsigned)pw * CPR);
+  const int ph = blockIdx.y, n = blockIdx.z;
+  const int c0 = cj * EPC;
+  float sc[EPC], sh[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+  for (int e = 0; e < EPC; ++e) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+  float best[EPC];
+  int bi[EPC];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+  for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+  const T* xn = x + (size_t)n * H * W * C + c0;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        int h = 2 * ph - 1 + r, w = 2 * pw - 1 + s;
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-          Chunk<T> v;
-          v.load(x + (((size_t)n * H + h) * W + w) * C + c0);
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            float a = fmaxf(v.v[e] * scale[c0 + e] + shift[c0 + e], 0.f);
-            if (a > best[e] || bi[e] < 0 || a != a) { best[e] = a; bi[e] = r * 3 + s; }
-          }
+    for (int s = 0; s < 3; ++s) {
+      int h = 2 * ph - 1 + r, w = 2 * pw - 1 + s;
+      if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+        Chunk<T> v;
+        v.load(xn + (size_t)(h * W + w) * C);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float a = fmaxf(v.v[e] * sc[e] + sh[e], 0.f);
+          if (a > best[e] || bi[e] < 0 || a != a) { best[e] = a; bi[e] = r * 3 + s; }
         }
       }
-    Chunk<T> o;
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) o.v[e] = best[e];
-    o.store(y + i * EPC);
-    if constexpr (EPC == 8) {
-      uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
-      uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
-      *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
-    } else {
-      *reinterpret_cast<uint32_t*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
+  const size_t i = ((size_t)(n * PH + ph) * PW + pw) * CPR + cj;
+  Chunk<T> o;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) o.v[e] = best[e];
+  o.store(y + i * EPC);
+  if constexpr (EPC == 8) {
+    uint32_t lo = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    uint32_t hi = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = make_uint2(lo, hi);
+  } else {
+    *reinterpret_cast<uint32_t*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
   }
 }
 template <typename T>
 int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N, int H, int W, int C, T* y,
                       uint8_t* idx, hipStream_t st) {
   int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(stem_bn_relu_pool_kernel<T>, dim3(ew_grid((size_t)N * PH * PW * (C / DT<T>::EPC))),
-                     dim3(EW_BLOCK), 0, st, x, scale, shift, N, H, W, C, PH, PW, y, idx);
+  ARG_CHECK(PH <= 65535 && N <= 65535, "stem_bn_relu_pool: grid %dx%d", PH, N);
+  hipLaunchKernelGGL(stem_bn_relu_pool_kernel<T>, dim3(ceil_div(PW * (C / DT<T>::EPC), 256), PH, N), dim3(256), 0, st, x, scale,
+                     shift, N, H, W, C, PH, PW, y, idx);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -677,33 +681,70 @@ int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, 
   return MMSKIN_OK;
 }
 
-// gradient of the 3x3/2 max-pool input at (n, h, w), chunk cj: sum of the pooled gradients whose argmax is this pixel
+// Stem backward works on pooled CELLS: the 2x2 input pixels (2ph..2ph+1, 2pw..2pw+1) receive gradient from the four
+// pooling windows (ph..ph+1, pw..pw+1) only, so one thread loads those four windows once (gradient + argmax bytes) and
+// the four pixels' x -- 12 independent 16-byte loads in flight instead of a dependent gather per pixel.
+//   pixel (2ph  ,2pw  ): window (ph,pw) tap 4
+//   pixel (2ph  ,2pw+1): (ph,pw) tap 5, (ph,pw+1) tap 3
+//   pixel (2ph+1,2pw  ): (ph,pw) tap 7, (ph+1,pw) tap 1
+//   pixel (2ph+1,2pw+1): (ph,pw) tap 8, (ph,pw+1) tap 6, (ph+1,pw) tap 2, (ph+1,pw+1) tap 0      (tap = 3*r + s)
+// Sums run in ascending (ph, pw) window order, like maxpool_bwd_kernel, so both formulations give identical bits.
 template <typename T>
-__device__ __forceinline__ void pool_grad_chunk(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, size_t n, int h, int w,
-                                                int cj, int C, int PH, int PW, float (&acc)[DT<T>::EPC]) {
+__device__ __forceinline__ void stem_cell_grad(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                               const float* __restrict__ scale, const float* __restrict__ shift, size_t n, int ph,
+                                               int pw, int cj, int H, int W, int C, int PH, int PW,
+                                               float (&d)[4][DT<T>::EPC], float (&xo)[4][DT<T>::EPC], bool (&ok)[4]) {
   constexpr int EPC = DT<T>::EPC;
+  const int c0 = cj * EPC;
+  const bool wv[4] = {true, pw + 1 < PW, ph + 1 < PH, (pw + 1 < PW) && (ph + 1 < PH)};
+  const size_t pbase = ((n * PH + ph) * PW + pw) * C + c0;
+  const size_t poff[4] = {0, (size_t)C, (size_t)PW * C, (size_t)(PW + 1) * C};
+  Chunk<T> g[4];
+  uint32_t iw[4][2];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-  for (int ph = h / 2; ph <= (h + 1) / 2; ++ph) {
-    if (ph >= PH) continue;
-    int r = h - (2 * ph - 1);
-    for (int pw = w / 2; pw <= (w + 1) / 2; ++pw) {
-      if (pw >= PW) continue;
-      int s = w - (2 * pw - 1);
-      const int tap = r * 3 + s;
-      size_t po = ((n * PH + ph) * PW + pw) * C + cj * EPC;
-      Chunk<T> g;
-      g.load(dpool + po);
-      uint32_t iw[2] = {0u, 0u};
+  for (int q = 0; q < 4; ++q) {
+    iw[q][0] = 0xffffffffu; iw[q][1] = 0xffffffffu;       // no tap matches a window that does not exist
+    if (wv[q]) {
+      g[q].load(dpool + pbase + poff[q]);
       if constexpr (EPC == 8) {
-        uint2 q = *reinterpret_cast<const uint2*>(idx + po);
-        iw[0] = q.x; iw[1] = q.y;
+        uint2 t = *reinterpret_cast<const uint2*>(idx + pbase + poff[q]);
+        iw[q][0] = t.x; iw[q][1] = t.y;
       } else {
-        iw[0] = *reinterpret_cast<const uint32_t*>(idx + po);
+        iw[q][0] = *reinterpret_cast<const uint32_t*>(idx + pbase + poff[q]);
       }
+    } else {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e)
-        if ((int)((iw[e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += g.v[e];
+      for (int e = 0; e < EPC; ++e) g[q].v[e] = 0.f;
+    }
+  }
+  const int h0 = 2 * ph, w0 = 2 * pw;
+  ok[0] = true; ok[1] = w0 + 1 < W; ok[2] = h0 + 1 < H; ok[3] = ok[1] && ok[2];
+  const size_t xbase = ((n * H + h0) * W + w0) * C + c0;
+  const size_t xoff[4] = {0, (size_t)C, (size_t)W * C, (size_t)(W + 1) * C};
+  Chunk<T> xv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (ok[p]) xv[p].load(x + xbase + xoff[p]);
+    else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xv[p].v[e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int t0 = (iw[0][e >> 2] >> (8 * (e & 3))) & 0xff, t1 = (iw[1][e >> 2] >> (8 * (e & 3))) & 0xff;
+    const int t2 = (iw[2][e >> 2] >> (8 * (e & 3))) & 0xff, t3 = (iw[3][e >> 2] >> (8 * (e & 3))) & 0xff;
+    const float g0 = g[0].v[e], g1 = g[1].v[e], g2 = g[2].v[e], g3 = g[3].v[e];
+    float a;
+    d[0][e] = (t0 == 4) ? g0 : 0.f;
+    a = (t0 == 5) ? g0 : 0.f; if (t1 == 3) a += g1; d[1][e] = a;
+    a = (t0 == 7) ? g0 : 0.f; if (t2 == 1) a += g2; d[2][e] = a;
+    a = (t0 == 8) ? g0 : 0.f; if (t1 == 6) a += g1; if (t2 == 2) a += g2; if (t3 == 0) a += g3; d[3][e] = a;
+    const float sc = scale[c0 + e], sh = shift[c0 + e];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      xo[p][e] = xv[p].v[e];
+      if (!(xv[p].v[e] * sc + sh > 0.f)) d[p][e] = 0.f;     // ReLU mask recomputed from x
     }
   }
 }
@@ -711,7 +752,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
                                                                      const T* __restrict__ x, const float* __restrict__ scale,
                                                                      const float* __restrict__ shift, int H, int W, int C, int PH,
-                                                                     int PW, size_t rows, ColGeom g, float* partial) {
+                                                                     int PW, size_t cells, ColGeom g, float* partial) {
   constexpr int EPC = DT<T>::EPC;
   __shared__ float red[2 * 256 * EPC];
   const int cx = threadIdx.x % g.CW, ry = threadIdx.x / g.CW;
@@ -721,21 +762,21 @@ __global__ __launch_bounds__(256) void stem_pool_bn_bwd_reduce_kernel(const T* _
   for (int e = 0; e < EPC; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
   if (ry < g.RL && col < g.CPR) {
     size_t r_end = (size_t)(blockIdx.x + 1) * g.RB;
-    if (r_end > rows) r_end = rows;
-    const int c0 = col * EPC;
+    if (r_end > cells) r_end = cells;
     for (size_t r = (size_t)blockIdx.x * g.RB + ry; r < r_end; r += g.RL) {
-      const int w = (int)(r % W); size_t t = r / W;
-      const int h = (int)(t % H);
-      const size_t n = t / H;
-      float dz[EPC];
-      pool_grad_chunk<T>(dpool, idx, n, h, w, col, C, PH, PW, dz);
-      Chunk<T> xv;
-      xv.load(x + (r * g.CPR + col) * EPC);
+      const unsigned r32 = (unsigned)r, t = r32 / (unsigned)PW;     // cells < 2^32 (checked by the launcher)
+      const int pw = (int)(r32 - t * (unsigned)PW);
+      const unsigned n = t / (unsigned)PH;
+      const int ph = (int)(t - n * (unsigned)PH);
+      float d[4][EPC], xv[4][EPC];
+      bool ok[4];
+      stem_cell_grad<T>(dpool, idx, x, scale, shift, n, ph, pw, col, H, W, C, PH, PW, d, xv, ok);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float d = (xv.v[e] * scale[c0 + e] + shift[c0 + e] > 0.f) ? dz[e] : 0.f;
-        acc[0][e] += d; acc[1][e] += d * xv.v[e];
-      }
+      for (int p = 0; p < 4; ++p)
+        if (ok[p]) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { acc[0][e] += d[p][e]; acc[1][e] += d[p][e] * xv[p][e]; }
+        }
     }
   }
   block_col_reduce<EPC, 2>(acc, cx, ry, g.CW, g.RL, col, g.CPR, C, partial, red);
@@ -744,48 +785,50 @@ template <typename T>
 int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N,
                             int H, int W, int C, float* partial, int* nrows_out, hipStream_t st) {
   ARG_CHECK(C % DT<T>::EPC == 0, "stem_pool_bn_bwd_reduce: C=%d", C);
-  const size_t rows = (size_t)N * H * W;
   const int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
-  ColGeom g = col_geom(rows, C, DT<T>::EPC);
+  const size_t cells = (size_t)N * PH * PW;
+  ARG_CHECK(cells < ((size_t)1 << 32), "stem_pool_bn_bwd_reduce: %zu cells", cells);
+  ColGeom g = col_geom(cells, C, DT<T>::EPC);
   hipLaunchKernelGGL(stem_pool_bn_bwd_reduce_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, st, dpool, idx, x, scale, shift, H, W, C, PH,
-                     PW, rows, g, partial);
+                     PW, cells, g, partial);
   HIP_CHECK_RET(hipGetLastError());
   *nrows_out = g.gx;
   return MMSKIN_OK;
 }
 template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void stem_pool_bn_bwd_apply_kernel(
+__global__ __launch_bounds__(256) void stem_pool_bn_bwd_apply_kernel(
     const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
-    int H, int W, int C, int PH, int PW, T* __restrict__ dx, size_t nchunks) {
+    int H, int W, int C, int PH, int PW, T* __restrict__ dx) {
   constexpr int EPC = DT<T>::EPC;
-  const int CPR = C / EPC;
-  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
-    const int cj = (int)(i % CPR), c0 = cj * EPC;
-    size_t t = i / CPR;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const size_t n = t / H;
-    float dz[EPC];
-    pool_grad_chunk<T>(dpool, idx, n, h, w, cj, C, PH, PW, dz);
-    Chunk<T> xv;
-    xv.load(x + i * EPC);
+  const unsigned CPR = C / EPC;
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;     // grid (ceil(PW*CPR / 256), PH, N): one thread per pooled cell and chunk
+  if (t >= (unsigned)PW * CPR) return;
+  const int pw = (int)(t / CPR), cj = (int)(t - (unsigned)pw * CPR), c0 = cj * EPC;
+  const int ph = blockIdx.y;
+  const size_t n = blockIdx.z;
+  float d[4][EPC], xv[4][EPC];
+  bool ok[4];
+  stem_cell_grad<T>(dpool, idx, x, scale, shift, n, ph, pw, cj, H, W, C, PH, PW, d, xv, ok);
+  const size_t xbase = ((n * H + 2 * ph) * W + 2 * pw) * C + c0;
+  const size_t xoff[4] = {0, (size_t)C, (size_t)W * C, (size_t)(W + 1) * C};
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const float d = (xv.v[e] * scale[c0 + e] + shift[c0 + e] > 0.f) ? dz[e] : 0.f;
-      xv.v[e] = cA[c0 + e] * d + cB[c0 + e] * xv.v[e] + cC[c0 + e];
+  for (int p = 0; p < 4; ++p)
+    if (ok[p]) {
+      Chunk<T> o;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o.v[e] = cA[c0 + e] * d[p][e] + cB[c0 + e] * xv[p][e] + cC[c0 + e];
+      o.store(dx + xbase + xoff[p]);
     }
-    xv.store(dx + i * EPC);
-  }
 }
 template <typename T>
 int stem_pool_bn_bwd_apply(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift,
                            const float* cA, const float* cB, const float* cC, int N, int H, int W, int C, T* dx, hipStream_t st) {
   ARG_CHECK(C % DT<T>::EPC == 0, "stem_pool_bn_bwd_apply: C=%d", C);
   const int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
-  const size_t nch = (size_t)N * H * W * (C / DT<T>::EPC);
-  hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dpool, idx, x, scale, shift, cA, cB,
-                     cC, H, W, C, PH, PW, dx, nch);
+  ARG_CHECK(PH <= 65535 && N <= 65535, "stem_pool_bn_bwd_apply: grid %dx%d", PH, N);
+  hipLaunchKernelGGL(stem_pool_bn_bwd_apply_kernel<T>, dim3(ceil_div(PW * (C / DT<T>::EPC), 256), PH, N), dim3(256), 0, st, dpool, idx,
+                     x, scale, shift, cA, cB, cC, H, W, C, PH, PW, dx);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
