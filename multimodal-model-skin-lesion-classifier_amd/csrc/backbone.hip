@@ -267,8 +267,21 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   if ((rc = p.ensure_table())) return rc;
   // stage weights (stem region needs zeros in its padding taps)
   HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
-  PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st,
-                                           (training || p.keep_raw_eval) ? nullptr : buffers, eps));
+  static const bool side_off_f = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
+  const bool use_side = !side_off_f && !p.prof.on;
+  if (use_side && (rc = p.side.init())) return rc;
+  const bool stage_aside = use_side && training;   // the stem only needs its own weights: the other layers are staged beside it
+  const float* fold = (training || p.keep_raw_eval) ? nullptr : buffers;
+  if (stage_aside) {
+    if ((rc = stage_weights<T>(p.table_dev, 1, p.max_stage_elems, params, wf, wd, training, st, fold, eps))) return rc;
+    HIP_CHECK_RET(hipEventRecord(p.side.f_ready, st));
+    HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.f_ready, 0));
+    if ((rc = stage_weights<T>(p.table_dev + 1, (int)p.units.size() - 1, p.max_stage_elems, params, wf, wd, training, p.side.s,
+                               fold, eps))) return rc;
+    HIP_CHECK_RET(hipEventRecord(p.side.f_staged, p.side.s));
+  } else {
+    PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st, fold, eps));
+  }
   if (!training && !p.keep_raw_eval) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st);
 
   auto bn_coeffs_on = [&](Unit& u, int stat_rows, float* ssum, float* ssq, double* red, hipStream_t s2) -> int {
@@ -285,9 +298,6 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   auto bn_coeffs = [&](Unit& u, int stat_rows) -> int {
     return bn_coeffs_on(u, stat_rows, stat_sum, stat_sq, reinterpret_cast<double*>(ws + p.off_red), st);
   };
-  static const bool side_off_f = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
-  const bool use_side = !side_off_f && !p.prof.on;
-  if (use_side && (rc = p.side.init())) return rc;
   float* stat_b_sum = reinterpret_cast<float*>(ws + p.off_stat_b);
   float* stat_b_sq = reinterpret_cast<float*>(ws + p.off_stat_b + p.stat_bytes);
 
@@ -306,6 +316,7 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   PROF(K_STEM_MISC, 0.0, 0.0, stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st));
 
   // ---- residual stages
+  if (stage_aside) HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.f_staged, 0));
   for (Block& b : p.blocks) {
     const T* in = reinterpret_cast<const T*>(ws + b.in_off);
     const T* cur = in;

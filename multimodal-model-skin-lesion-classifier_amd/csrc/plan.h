@@ -47,6 +47,7 @@ struct SideStream {
   hipEvent_t done[3] = {nullptr, nullptr, nullptr};    // side: the wgrad reading buffer i has finished
   bool done_valid[3] = {false, false, false};
   hipEvent_t f_ready = nullptr, f_done = nullptr;      // forward: block input ready / downsample branch finished
+  hipEvent_t f_staged = nullptr;                       // forward: weights of the residual stages staged (beside the stem)
   int init() {
     if (s) return MMSKIN_OK;
     int least = 0, greatest = 0;
@@ -62,12 +63,13 @@ struct SideStream {
     }
     HIP_CHECK_RET(hipEventCreateWithFlags(&f_ready, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&f_done, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&f_staged, hipEventDisableTiming));
     return MMSKIN_OK;
   }
   void destroy() {
     if (!s) return;
     for (int i = 0; i < 3; ++i) { (void)hipEventDestroy(ready[i]); (void)hipEventDestroy(done[i]); }
-    (void)hipEventDestroy(f_ready); (void)hipEventDestroy(f_done);
+    (void)hipEventDestroy(f_ready); (void)hipEventDestroy(f_done); (void)hipEventDestroy(f_staged);
     (void)hipStreamDestroy(s);
     s = nullptr;
   }
