@@ -522,20 +522,16 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     if (b.seg_done >= 0 && (rc = p.segment_done(b.seg_done, st, use_side))) return rc;
   }
 
-  // join: the stem reuses the scratch buffers and the slab the side stream has been working on
-  for (int i = 0; i < 3; ++i)
-    if ((rc = acquire(i))) return rc;
-
-  // ---- stem: g = grad wrt pooled activation
+  // ---- stem: g = grad wrt pooled activation.  Its BatchNorm backward touches none of the buffers the side stream's
+  // weight-gradient GEMMs are still reading (dX ring, forward activations) or writing (slab), so it runs on the main
+  // stream BESIDE the tail of layer1's wgrads; the stem's own wgrad needs the slab and queues behind them on the side stream.
   Unit& u0 = p.units[0];
-  T* dyfull = S[2];
   T* dx0 = S[3];
   {   // max-pool + ReLU + BatchNorm backward without materialising the full-resolution pooled gradient
     float* c0 = reinterpret_cast<float*>(ws + u0.coef_off);
     const T* x0 = reinterpret_cast<const T*>(ws + u0.x_off);
     float* cB = cA + 64; float* cC = cA + 128;
     int nr = 0;
-    (void)dyfull;
     p.prof.begin(K_BN_BWD, st);
     rc = stem_pool_bn_bwd_reduce<T>(g, ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
     if (!rc) rc = bn_bwd_finalize(partial, nr, 64, (double)u0.rows(), params + u0.g_off, c0 + 128, c0 + 192, grads + u0.g_off,
@@ -546,10 +542,22 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     if (rc) return rc;
   }
   float* dwv = reinterpret_cast<float*>(ws + p.off_dwv);
-  PROF(K_WGRAD, conv_flops(u0.s), 0.0,
-       launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4),
-                                 slab, dwv, st));
-  if ((rc = stem_wgrad_unpack(dwv, grads + u0.w_off, st))) return rc;
+  hipStream_t wst = st;
+  if (use_side) {
+    HIP_CHECK_RET(hipEventRecord(p.side.ready[0], st));
+    HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.ready[0], 0));
+    wst = p.side.s;
+  }
+  p.prof.begin(K_WGRAD, st);
+  rc = launch_stem_conv_wgrad<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, dx0, reinterpret_cast<const T*>(ws + p.off_img4), slab, dwv, wst);
+  p.prof.end(st);
+  if (p.prof.on) p.prof.flops[K_WGRAD] += conv_flops(u0.s);
+  if (rc) return rc;
+  if ((rc = stem_wgrad_unpack(dwv, grads + u0.w_off, wst))) return rc;
+  if (use_side) {   // final join: everything the side stream was given has finished before backward's last event
+    HIP_CHECK_RET(hipEventRecord(p.side.done[0], p.side.s));
+    HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.done[0], 0));
+  }
   return p.segment_done((int)p.segments.size() - 1, st, false);
 }
 
