@@ -342,15 +342,54 @@ static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int
 #define WG_DIRECT_SPLITS 32   // more splits than this are pre-reduced to WG_GROUPS partial slabs first
 #define WG_GROUPS 64        // upper bound; small outputs use more groups so the first stage still fills the chip
 
+// sum the nsplit slabs [Cout][Ktot] (optionally through G group partials stored behind them) into the OIHW gradient
+static int reduce_slabs(float* slab, int nsplit, int Cout, int Ktot, float* dw, int C_for_layout, int ntaps_for_layout,
+                        int cout_valid, int cin_valid, hipStream_t st) {
+  size_t total = (size_t)Cout * Ktot;
+  const int total4 = (int)(total / 4);
+  const float* src = slab;
+  int nsrc = nsplit;
+  if (nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction to G <= WG_GROUPS partial slabs
+    float* slab2 = slab + (size_t)nsplit * total;
+    // >= 256k threads where the output allows it, <= 32 rows per thread, at least 2 rows per group
+    int G = ceil_div(262144, total4);
+    const int g_lo = ceil_div(nsplit, 32), g_hi = nsplit / 2 < WG_GROUPS ? nsplit / 2 : WG_GROUPS;
+    if (G < g_lo) G = g_lo;
+    if (G > g_hi) G = g_hi;
+    const int per = ceil_div(nsplit, G);
+    G = ceil_div(nsplit, per);
+    hipLaunchKernelGGL(wgrad_slab_group_kernel, dim3(ceil_div(total4, 256), G), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(slab2), nsplit, total4, per);
+    HIP_CHECK_RET(hipGetLastError());
+    src = slab2;
+    nsrc = G;
+  }
+  const int coutv = cout_valid > 0 ? cout_valid : Cout, cv = cin_valid > 0 ? cin_valid : C_for_layout;
+  if (C_for_layout % 4 == 0) {
+    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
+                       dw, nsrc, Cout, C_for_layout, ntaps_for_layout, coutv, cv);
+  } else {
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, Cout, C_for_layout,
+                       ntaps_for_layout, coutv, cv);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 template <typename T>
 static size_t slab_bytes(int M, int Cout, int Ktot, int ntaps) {
   int BO, BKK, ns, mps;
   wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps, ntaps);
   return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * Cout * Ktot * sizeof(float);
 }
+static size_t wgrad3_slab_bytes(const ConvShape& s);   // all-taps 3x3 path below
 size_t conv_wgrad_slab_bytes(const ConvShape& s) {
   int M = s.N * s.OH() * s.OW(), K = s.kh * s.kw * s.Cin;
   size_t a = slab_bytes<float>(M, s.Cout, K, s.kh * s.kw), b = slab_bytes<bf16_t>(M, s.Cout, K, s.kh * s.kw);
+  const size_t c = wgrad3_slab_bytes(s);
+  if (c > b) b = c;
   return a > b ? a : b;
 }
 size_t stem_wgrad_slab_bytes(int N, int OH, int OW) {
@@ -388,43 +427,221 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   else if (BKK == 128) rc = launch_wg<T, 64, 128, 2>(a, st);
   else rc = launch_wg<T, 64, 64, 4>(a, st);
   if (rc) return rc;
-  size_t total = (size_t)a.Cout * a.Ktot;
-  const int total4 = (int)(total / 4);
-  const float* src = a.slab;
-  int nsrc = a.nsplit;
-  if (a.nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction to G <= WG_GROUPS partial slabs
-    float* slab2 = a.slab + (size_t)a.nsplit * total;
-    // >= 256k threads where the output allows it, <= 32 rows per thread, at least 2 rows per group
-    int G = ceil_div(262144, total4);
-    const int g_lo = ceil_div(a.nsplit, 32), g_hi = a.nsplit / 2 < WG_GROUPS ? a.nsplit / 2 : WG_GROUPS;
-    if (G < g_lo) G = g_lo;
-    if (G > g_hi) G = g_hi;
-    const int per = ceil_div(a.nsplit, G);
-    G = ceil_div(a.nsplit, per);
-    hipLaunchKernelGGL(wgrad_slab_group_kernel, dim3(ceil_div(total4, 256), G), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(a.slab), reinterpret_cast<float4*>(slab2), a.nsplit, total4, per);
-    HIP_CHECK_RET(hipGetLastError());
-    src = slab2;
-    nsrc = G;
+  return reduce_slabs(a.slab, a.nsplit, a.Cout, a.Ktot, dw, C_for_layout, ntaps_for_layout, cout_valid, cin_valid, st);
+}
+
+
+// ------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1, all taps per workgroup
+// The tapped kernel above gives every (cout tile, tap x cin tile) its own workgroup, so a 3x3 layer streams dY and the
+// gathered input through L2 -> LDS nine times (layer1.conv2: 1.85 GB per launch, 32 FLOP per LDS-staged byte).  Here a
+// workgroup owns dW[64 cout][9 taps][64 cin]: a stage is R whole image rows (R*W <= 64 pixels); their dY rows and the
+// (R+2) x (W+2) zero-padded INPUT WINDOW are staged once, and tap (ty, tx) of pixel (r, x) is window row
+// (r+ty)*(W+2) + x+tx -- a constant row offset per tap, no masks, no gather.  LDS rows are 64 channels + 16 B of
+// padding (pitch 144 B: conflict-free for the transposing reads without an XOR swizzle, so tap offsets stay additive).
+// 72 MFMAs per wave and stage against ~30 KB of loads (140 FLOP/B).  bf16 only; partial slabs as above.
+struct Wgrad3Args {
+  const bf16_t* dy; const bf16_t* in; float* slab;
+  int N, H, W, C, Cout;
+  int R, spi;                       // image rows per stage, stages per image
+  int total_stages, stages_per_split, nsplit;
+  int nblk_o, nblk_c;
+  int yrows;                        // (R+2)*(W+2)
+};
+#define W3_PITCH 144
+#define W3_XROWS 64
+#define W3_YROWS 176
+#define W3_LDS_BYTES (2 * (W3_XROWS + W3_YROWS) * W3_PITCH)
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* Xs = smem3;
+  unsigned char* Ys = smem3 + 2 * W3_XROWS * W3_PITCH;
+  constexpr int X_BYTES = W3_XROWS * W3_PITCH, Y_BYTES = W3_YROWS * W3_PITCH;
+  const int tid = threadIdx.x;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int cb = tile % p.nblk_c; tile /= p.nblk_c;
+  const int ob = tile % p.nblk_o;
+  const int split = tile / p.nblk_o;
+  const int o0 = ob * 64, c0 = cb * 64;
+  const int W = p.W, H = p.H, W2 = W + 2, R = p.R;
+  const int st_begin = split * p.stages_per_split;
+  const int st_end = min(p.total_stages, st_begin + p.stages_per_split);
+  int img = st_begin / p.spi, y0 = (st_begin - img * p.spi) * R;
+
+  // ---- loaders.  dY: 64 pixel slots x 8 chunks = 2 per thread; window: up to 176 rows x 8 chunks = 6 per thread
+  const int ch = tid & 7;
+  int x_r[2], x_pix[2];
+  bool x_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = (tid >> 3) + 32 * i;
+    x_r[i] = slot / W;
+    x_pix[i] = slot;                                   // = r*W + x: pixel offset inside the stage's rows
+    x_ok[i] = slot < R * W;
   }
-  const int coutv = cout_valid > 0 ? cout_valid : a.Cout, cv = cin_valid > 0 ? cin_valid : C_for_layout;
-  if (C_for_layout % 4 == 0) {
-    hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(ceil_div(total4, 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(src),
-                       dw, nsrc, a.Cout, C_for_layout, ntaps_for_layout, coutv, cv);
-  } else {
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, src, dw, nsrc, a.Cout, C_for_layout,
-                       ntaps_for_layout, coutv, cv);
+  int y_wr[6], y_pix[6];
+  bool y_ok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j = (tid >> 3) + 32 * i;
+    const int wr = j / W2, wc = j - wr * W2;
+    y_wr[i] = wr - 1;                                  // image row relative to y0
+    y_pix[i] = (wr - 1) * W + (wc - 1);
+    y_ok[i] = j < p.yrows && wc >= 1 && wc <= W;
   }
+  const u32x4_t z4 = {0, 0, 0, 0};
+  u32x4_t rx0 = z4, rx1 = z4, ry0 = z4, ry1 = z4, ry2 = z4, ry3 = z4, ry4 = z4, ry5 = z4;
+#define W3_LOADX(i, Rg)                                                                                         \
+  {                                                                                                             \
+    const bool ok = x_ok[i] && (y0 + x_r[i] < H);                                                               \
+    const bf16_t* src = p.dy + ((size_t)((img * H + y0) * W + x_pix[i]) * p.Cout + o0 + ch * 8);                \
+    Rg = z4;                                                                                                    \
+    if (ok) Rg = *reinterpret_cast<const u32x4_t*>(src);                                                        \
+  }
+#define W3_LOADY(i, Rg)                                                                                         \
+  {                                                                                                             \
+    const bool ok = y_ok[i] && (unsigned)(y0 + y_wr[i]) < (unsigned)H;                                          \
+    const bf16_t* src = p.in + ((int64_t)((img * H + y0) * W + y_pix[i]) * p.C + c0 + ch * 8);                  \
+    Rg = z4;                                                                                                    \
+    if (ok) Rg = *reinterpret_cast<const u32x4_t*>(src);                                                        \
+  }
+#define W3_LOAD_STAGE()                                                                                         \
+  do {                                                                                                          \
+    W3_LOADX(0, rx0) W3_LOADX(1, rx1)                                                                           \
+    W3_LOADY(0, ry0) W3_LOADY(1, ry1) W3_LOADY(2, ry2) W3_LOADY(3, ry3) W3_LOADY(4, ry4) W3_LOADY(5, ry5)       \
+  } while (0)
+#define W3_STX(buf, i, Rg) *reinterpret_cast<u32x4_t*>(Xs + (buf) * X_BYTES + ((tid >> 3) + 32 * i) * W3_PITCH + ch * 16) = Rg;
+#define W3_STY(buf, i, Rg)                                                                                      \
+  if ((tid >> 3) + 32 * i < W3_YROWS) *reinterpret_cast<u32x4_t*>(Ys + (buf) * Y_BYTES + ((tid >> 3) + 32 * i) * W3_PITCH + ch * 16) = Rg;
+#define W3_STORE_STAGE(buf)                                                                                     \
+  do {                                                                                                          \
+    W3_STX(buf, 0, rx0) W3_STX(buf, 1, rx1)                                                                     \
+    W3_STY(buf, 0, ry0) W3_STY(buf, 1, ry1) W3_STY(buf, 2, ry2) W3_STY(buf, 3, ry3) W3_STY(buf, 4, ry4) W3_STY(buf, 5, ry5) \
+  } while (0)
+#define W3_ADVANCE()                                                                                            \
+  do { y0 += R; if (y0 >= H) { y0 = 0; ++img; } } while (0)
+
+  // ---- fragment addressing (transposing reads: lane (q, pp) addresses row q, columns 4pp..4pp+3 of a 4 x 16 block)
+  const int wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  const int q = l15 >> 2, pp = l15 & 3;
+  const int wo = wid >> 1, wk = wid & 1;               // wave: cout half, cin half
+  int xa[2][2], ya[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 32 * ks + 8 * g + q + 4 * h;       // pixel slot
+      xa[ks][h] = k * W3_PITCH + (wo * 32 + 4 * pp) * 2;
+      const int r = k / W, x = k - r * W;
+      const int brow = k < R * W ? r * W2 + x : 0;     // slots past the stage have dY = 0: any finite window row will do
+      ya[ks][h] = brow * W3_PITCH + (wk * 32 + 4 * pp) * 2;
+    }
+  f32x4_t acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define W3_COMPUTE(buf)                                                                                         \
+  do {                                                                                                          \
+    const unsigned char* Xb = Xs + (buf) * X_BYTES;                                                             \
+    const unsigned char* Yb = Ys + (buf) * Y_BYTES;                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+      uint4 fx[2];                                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                           \
+        uint2 lo = lds_read_tr16_b64(Xb + xa[ks][0] + j * 32);                                                  \
+        uint2 hi = lds_read_tr16_b64(Xb + xa[ks][1] + j * 32);                                                  \
+        fx[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);                                                             \
+      }                                                                                                         \
+      _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                           \
+        const int tb = ((t / 3) * W2 + (t % 3)) * W3_PITCH;                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
+          uint2 lo = lds_read_tr16_b64(Yb + ya[ks][0] + tb + i * 32);                                           \
+          uint2 hi = lds_read_tr16_b64(Yb + ya[ks][1] + tb + i * 32);                                           \
+          const uint4 fy = make_uint4(lo.x, lo.y, hi.x, hi.y);                                                  \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                         \
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fy),            \
+                                                                   __builtin_bit_cast(bf16x8_t, fx[j]), acc[t][i][j], 0, 0, 0); \
+        }                                                                                                       \
+      }                                                                                                         \
+    }                                                                                                           \
+  } while (0)
+
+  if (st_begin < st_end) { W3_LOAD_STAGE(); W3_STORE_STAGE(0); }
+  __syncthreads();
+  for (int s = st_begin; s < st_end; ++s) {
+    const int cur = (s - st_begin) & 1;
+    if (s + 1 < st_end) { W3_ADVANCE(); W3_LOAD_STAGE(); }     // in flight while this stage is multiplied
+    W3_COMPUTE(cur);
+    if (s + 1 < st_end) W3_STORE_STAGE(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D[cin][cout]: lane holds cout = l15, cin = 4g + reg -> float4 along k in the slab [cout][tap*C + cin]
+  const int Ktot = 9 * p.C;
+  float* slab = p.slab + (size_t)split * p.Cout * Ktot;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cout = o0 + wo * 32 + j * 16 + l15;
+        const int kidx = t * p.C + c0 + wk * 32 + i * 16 + g * 4;
+        *reinterpret_cast<float4*>(slab + (size_t)cout * Ktot + kidx) =
+            make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
+      }
+}
+
+static bool wgrad3_plan(const ConvShape& s, Wgrad3Args& a) {
+  static const int enabled = env_int("MMSKIN_WGRAD_3X3", 1);
+  if (!enabled || s.kh != 3 || s.kw != 3 || s.stride != 1 || s.pad != 1) return false;
+  if (s.Cin % 64 || s.Cout % 64 || s.W > 64 || s.W < 1) return false;
+  int R = 64 / s.W;
+  if (R > s.H) R = s.H;
+  if ((R + 2) * (s.W + 2) > W3_YROWS) return false;
+  a.N = s.N; a.H = s.H; a.W = s.W; a.C = s.Cin; a.Cout = s.Cout;
+  a.R = R; a.spi = ceil_div(s.H, R);
+  a.total_stages = s.N * a.spi;
+  a.nblk_o = s.Cout / 64; a.nblk_c = s.Cin / 64;
+  a.yrows = (R + 2) * (s.W + 2);
+  const int tiles = a.nblk_o * a.nblk_c;
+  static const int target = env_int("MMSKIN_WGRAD3_BLOCKS", 512);      // one round of 2 workgroups per CU
+  int ns = target / tiles > 0 ? target / tiles : 1;
+  if (ns > a.total_stages) ns = a.total_stages;
+  a.stages_per_split = ceil_div(a.total_stages, ns);
+  a.nsplit = ceil_div(a.total_stages, a.stages_per_split);
+  return true;
+}
+static size_t wgrad3_slab_bytes(const ConvShape& s) {
+  Wgrad3Args a = {};
+  if (!wgrad3_plan(s, a)) return 0;
+  return (size_t)(a.nsplit + (a.nsplit > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * s.Cout * 9 * s.Cin * sizeof(float);
+}
+static int launch_wgrad3(const ConvShape& s, Wgrad3Args& a, const bf16_t* dout, const bf16_t* in, float* slab, float* dw,
+                         hipStream_t st, int cout_valid, int cin_valid) {
+  a.dy = dout; a.in = in; a.slab = slab;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      W3_LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad3x3_kernel, dim3(a.nblk_o * a.nblk_c * a.nsplit), dim3(256), W3_LDS_BYTES, st, a);
   HIP_CHECK_RET(hipGetLastError());
-  return MMSKIN_OK;
+  return reduce_slabs(slab, a.nsplit, s.Cout, 9 * s.Cin, dw, s.Cin, 9, cout_valid, cin_valid, st);
 }
 
 template <typename T>
 int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* slab, float* dw_oihw,
                       hipStream_t st, int cout_valid, int cin_valid) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "wgrad: too many taps");
+  if constexpr (sizeof(T) == 2) {
+    Wgrad3Args a3 = {};
+    if (wgrad3_plan(s, a3)) return launch_wgrad3(s, a3, dout, in, slab, dw_oihw, st, cout_valid, cin_valid);
+  }
   WgradArgs a = {};
   a.dy = dout; a.in = in; a.slab = slab;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;

@@ -28,6 +28,10 @@ CONV_CASES = [
     (2, 128, 15, 13, 128, 3, 2, 1),    # 3x3 stride 2, odd sizes
     (2, 256, 14, 14, 512, 1, 2, 0),    # downsample 1x1 stride 2
     (1, 512, 7, 7, 512, 3, 1, 1),      # layer4-style, M < one row block
+    (2, 64, 56, 56, 64, 3, 1, 1),      # all-taps 3x3 wgrad: one image row per stage
+    (3, 128, 28, 28, 64, 3, 1, 1),     # ... two rows per stage, two cin tiles
+    (5, 64, 14, 14, 128, 3, 1, 1),     # ... four rows per stage, ragged last stage of every image (14 = 4+4+4+2)
+    (2, 64, 9, 13, 64, 3, 1, 1),       # ... odd sizes (4 rows of 13 per stage)
 ]
 
 
