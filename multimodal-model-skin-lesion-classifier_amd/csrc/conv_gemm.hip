@@ -481,8 +481,10 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   a.Sy = 1; a.Sx = 1; a.OS = s.stride;
   a.OHf = s.H; a.OWf = s.W;
   a.ncls = 0;
-  for (int ph = 0; ph < s.stride; ++ph)
-    for (int pw = 0; pw < s.stride; ++pw) {
+  // Parity classes from the heaviest down (3x3, stride 2, pad 1: 4, 2, 2, 1 taps): the long-K workgroups start first and the
+  // short ones fill the tail of the launch instead of the other way round.
+  for (int ph = s.stride - 1; ph >= 0; --ph)
+    for (int pw = s.stride - 1; pw >= 0; --pw) {
       TapClass c = {};
       c.a_dim = (s.H - ph + s.stride - 1) / s.stride;
       c.b_dim = (s.W - pw + s.stride - 1) / s.stride;
