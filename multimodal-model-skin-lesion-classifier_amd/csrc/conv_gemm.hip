@@ -406,8 +406,9 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
   static const int nst1_min_blocks = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS"); return v ? atoi(v) : 640; }();
+  static const int nst1_min_blocks_epi = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS_EPI"); return v ? atoi(v) : 800; }();   // fused-epilogue launches: 168 VGPRs = 3 workgroups/CU = 768 single-buffer slots; a 784-workgroup launch would spill into a second round
   const int bn_sel = (a.Cout % 128 == 0) ? 128 : 64;
-  const bool one = a.total_mblk * (a.Cout / bn_sel) > nst1_min_blocks;
+  const bool one = a.total_mblk * (a.Cout / bn_sel) > (epi ? nst1_min_blocks_epi : nst1_min_blocks);
 #define GO(BNv, E) (one ? launch_cfg<T, CONV_BM, BNv, 2, 2, E, 1>(a, st) : launch_cfg<T, CONV_BM, BNv, 2, 2, E, 2>(a, st))
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
