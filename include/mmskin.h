@@ -75,6 +75,10 @@ int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, c
  * last_conv_export returns that conv's output [N][C][OH][OW] (fp32) and last_conv_grad the gradient of the pooled
  * features w.r.t. it for a given d(score)/d(features) [N][C].  ResNet plans only. */
 int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value);
+/* option "reuse_staged" = 1 (serving): the caller vouches that parameters and BatchNorm buffers are unchanged since the
+ * previous eval forward on this plan and workspace; the BN-folded staged weights and coefficient table already in the
+ * workspace are then reused instead of rebuilt (ResNet plans; others restage).  Any training-mode or keep_raw_eval
+ * forward invalidates the staged copy by itself. */
 /* per-step device pointers: key "sd_mask" (EfficientNet plans) = fp32 [n_residual_blocks][batch] keep/scale factors of
  * torchvision's StochasticDepth(p, "row") for this training step (0 or 1/(1-p)); NULL disables stochastic depth */
 int mmskin_backbone_set_pointer(mmskin_backbone_t h, const char* key, const void* device_ptr);

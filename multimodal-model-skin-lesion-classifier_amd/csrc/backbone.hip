@@ -212,12 +212,12 @@ int build_plan(Plan& p) {
 // no raw conv output exists (loadImageModelClassifier.py backbones under model.eval(): model_metrics.py:50-62).
 template <typename T>
 int forward_eval(Plan& p, const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
-                 float* features, hipStream_t st) {
+                 float* features, hipStream_t st, bool reuse_table) {
   const float eps = 1e-5f;
   T* wf = reinterpret_cast<T*>(ws + p.off_wf);
   int rc, maxC = 64;
   for (const Unit& u : p.units) maxC = u.s.Cout > maxC ? u.s.Cout : maxC;
-  PROF(K_BN_FWD, 0.0, 0.0, bn_eval_table(p.table_dev, (int)p.units.size(), maxC, params, buffers, ws, eps, st));
+  if (!reuse_table) PROF(K_BN_FWD, 0.0, 0.0, bn_eval_table(p.table_dev, (int)p.units.size(), maxC, params, buffers, ws, eps, st));
   auto shift_of = [&](const Unit& u) { return reinterpret_cast<const float*>(ws + u.coef_off) + u.s.Cout; };
   // stem: the 7x7 conv keeps its own BN + ReLU + max-pool kernel (one pass over the largest activation)
   Unit& u0 = p.units[0];
@@ -265,8 +265,11 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   float* stat_sq = reinterpret_cast<float*>(ws + p.off_stat + p.stat_bytes);
   int rc;
   if ((rc = p.ensure_table())) return rc;
+  const bool folded_eval = !training && !p.keep_raw_eval;
+  const bool reuse = folded_eval && p.reuse_staged && p.staged_eval_ws == ws;
+  p.staged_eval_ws = folded_eval ? ws : nullptr;
   // stage weights (stem region needs zeros in its padding taps)
-  HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
+  if (!reuse) HIP_CHECK_RET(hipMemsetAsync(wf + p.units[0].wf_off, 0, 64 * 256 * sizeof(T), st));
   static const bool side_off_f = [] { const char* v = getenv("MMSKIN_NO_SIDE_STREAM"); return v && atoi(v) != 0; }();
   const bool use_side = !side_off_f && !p.prof.on;
   if (use_side && (rc = p.side.init())) return rc;
@@ -279,10 +282,10 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
     if ((rc = stage_weights<T>(p.table_dev + 1, (int)p.units.size() - 1, p.max_stage_elems, params, wf, wd, training, p.side.s,
                                fold, eps))) return rc;
     HIP_CHECK_RET(hipEventRecord(p.side.f_staged, p.side.s));
-  } else {
+  } else if (!reuse) {
     PROF(K_STAGE, 0.0, 0.0, stage_weights<T>(p.table_dev, (int)p.units.size(), p.max_stage_elems, params, wf, wd, training, st, fold, eps));
   }
-  if (!training && !p.keep_raw_eval) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st);
+  if (folded_eval) return forward_eval<T>(p, image, norm6, params, buffers, ws, features, st, reuse);
 
   auto bn_coeffs_on = [&](Unit& u, int stat_rows, float* ssum, float* ssq, double* red, hipStream_t s2) -> int {
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
@@ -724,6 +727,7 @@ int mmskin_backbone_forward_u8(mmskin_backbone_t h, const uint8_t* image_nhwc, c
 int mmskin_backbone_set_option(mmskin_backbone_t h, const char* key, int value) {
   ARG_CHECK(h && key, "backbone_set_option: null argument");
   if (!strcmp(key, "keep_raw_eval")) { h->plan->keep_raw_eval = value != 0; return MMSKIN_OK; }
+  if (!strcmp(key, "reuse_staged")) { h->plan->reuse_staged = value != 0; return MMSKIN_OK; }
   mmskin_set_error("backbone_set_option: unknown option '%s'", key);
   return MMSKIN_ERR_ARG;
 }

@@ -130,6 +130,11 @@ struct PlanBase {
   // Grad-CAM support: the raw output of the network's last nn.Conv2d and d(features)/d(that output)
   // for an eval-mode forward that kept raw conv outputs (option "keep_raw_eval"); plans without it: unsupported
   bool keep_raw_eval = false;
+  // Serving: option "reuse_staged" = the caller vouches that parameters and BatchNorm buffers are unchanged
+  // since the previous folded eval forward on this workspace, so the staged (BN-folded) weights and the coefficient
+  // table already in it are reused instead of rebuilt.  Plans that do not implement it simply restage.
+  bool reuse_staged = false;
+  const void* staged_eval_ws = nullptr;
   virtual int last_conv_shape(int*, int*, int*) const { return MMSKIN_ERR_UNSUPPORTED; }
   virtual int last_conv_export(const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }
   virtual int last_conv_grad(const float*, const unsigned char*, float*, hipStream_t) { return MMSKIN_ERR_UNSUPPORTED; }

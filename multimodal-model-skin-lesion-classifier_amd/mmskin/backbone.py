@@ -63,6 +63,7 @@ class _Plan:
         self.param_numel = lib.mmskin_backbone_param_numel(h)
         self.ws_bytes = lib.mmskin_backbone_workspace_bytes(h)
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device) if device is not None else None
+        self.eval_key = None      # (param version, buffer version, arena address) of the last folded eval forward
 
     def last_conv_shape(self):
         c, oh, ow = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -119,6 +120,14 @@ class _BackboneFn(torch.autograd.Function):
         plan = module._plan_for(N, H, W, image.device)
         shape = (N, plan.feat_dim) if plan.out_hw == (1, 1) else (N, plan.feat_dim) + plan.out_hw
         feats = torch.empty(shape, device=image.device, dtype=torch.float32)
+        # serving: an eval forward whose parameters / BatchNorm buffers are untouched since the previous eval forward on this
+        # plan reuses the BN-folded staged weights already in the workspace (tensor version counters; a training forward
+        # updates the running statistics behind torch's back, so it always invalidates)
+        # (Parameters alias the flat arena through .data, which does not share its version counter: sum the parameters' own --
+        # counters only grow, so the sum changes whenever any of them does.)
+        key = None if training else (sum(p._version for p in params), module._flat_b._version, module._flat_p.data_ptr())
+        call("mmskin_backbone_set_option", plan.handle, b"reuse_staged", int(key is not None and plan.eval_key == key))
+        plan.eval_key = key
         if u8:
             norm6 = (ctypes.c_float * 6)(*module.input_mean, *module.input_std)
             call("mmskin_backbone_forward_u8", plan.handle, ptr(image), norm6, ptr(module._flat_p), ptr(module._flat_b),

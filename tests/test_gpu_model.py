@@ -321,3 +321,33 @@ def test_gradcam_consumer_on_last_conv():
     # without hooks the folded inference path is used again and gives the same logits
     with torch.no_grad():
         assert torch.allclose(hip(img.to(DEV), meta.to(DEV)).cpu(), o_c, rtol=1e-3, atol=1e-4)
+
+
+def test_eval_forward_reuses_staged_weights_only_while_unchanged():
+    """Serving path: repeated eval forwards reuse the BN-folded staged weights; an in-place parameter
+    update or a training forward (running statistics move) must be picked up by the next eval forward."""
+    from mmskin.backbone import HipResNet
+    os.environ["MMSKIN_BACKBONE_DTYPE"] = "fp32"
+    torch.manual_seed(3)
+    enc = HipResNet("resnet-18").to(DEV)
+    x = torch.randn(4, 3, 64, 64, device=DEV)
+    enc.eval()
+    with torch.no_grad():
+        a = enc(x).clone()
+        b = enc(x).clone()                       # second call: staged weights reused
+        assert torch.equal(a, b)
+        enc.conv1.weight.mul_(1.5)               # version bump -> restaged
+        c = enc(x).clone()
+        assert rel_err(c, a) > 1e-3
+        fresh = HipResNet("resnet-18").to(DEV)
+        fresh.load_state_dict(enc.state_dict())
+        fresh.eval()
+        assert rel_err(c, fresh(x)) < 1e-5
+    enc.train()
+    enc(x)                                       # updates running_mean / running_var inside the C call
+    enc.eval()
+    with torch.no_grad():
+        d = enc(x).clone()
+        fresh.load_state_dict(enc.state_dict())
+        assert rel_err(d, fresh(x)) < 1e-5
+        assert rel_err(d, c) > 1e-4
