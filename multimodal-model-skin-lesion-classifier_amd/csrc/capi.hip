@@ -212,13 +212,13 @@ int stem_bwd_op(const float* dy, const float* x, const float* w, const float* ga
   int rc;
   if ((rc = stem_fwd_core<T>(s, x, w, gamma, beta, N, H, W, eps, st))) return rc;
   if ((rc = nchw_to_nhwc<T>(dy, N, 64, g.PH, g.PW, s.dpool, st))) return rc;
-  if ((rc = maxpool_bwd<T>(s.dpool, s.idx, N, g.OH, g.OW, 64, s.dyfull, st))) return rc;
+  // the plans' fused path: max-pool + ReLU + BatchNorm backward on pooled cells, no full-resolution pooled gradient
   int nr = 0;
-  if ((rc = bn_bwd_reduce<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, rows, 64, s.partial, &nr, st))) return rc;
+  if ((rc = stem_pool_bn_bwd_reduce<T>(s.dpool, s.idx, s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.partial, &nr, st))) return rc;
   if ((rc = bn_bwd_finalize(s.partial, nr, 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
                             dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, s.red, st))) return rc;
-  if ((rc = bn_bwd_apply<T>(s.dyfull, s.x0, nullptr, s.coef, s.coef + 64, MASK_FROM_X, s.coef + 256, s.coef + 320,
-                            s.coef + 384, s.dx0, (T*)nullptr, rows, 64, st))) return rc;
+  if ((rc = stem_pool_bn_bwd_apply<T>(s.dpool, s.idx, s.x0, s.coef, s.coef + 64, s.coef + 256, s.coef + 320, s.coef + 384, N, g.OH,
+                                      g.OW, 64, s.dx0, st))) return rc;
   if ((rc = launch_stem_conv_wgrad<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.dx0, s.img4, s.slab, s.dwv, st))) return rc;
   return stem_wgrad_unpack(s.dwv, dw, st);
 }

@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const int wid_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
   const int abl = p.ablate;                                     // timing experiments only (0 in production)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 // The DMA is issued from inline asm: through the builtin, hipcc models it as an LDS store that may alias
 // every ds_read and drains s_waitcnt vmcnt(0) in front of the MFMA loop, which serialised load and

@@ -102,7 +102,7 @@ def test_batchnorm_train_forward_backward(shape, relu, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("hw", [(64, 64), (48, 80)])
+@pytest.mark.parametrize("hw", [(64, 64), (48, 80), (50, 70), (37, 45)])   # the last two: odd conv / pool output sizes
 def test_stem_forward_backward(hw, dtype):
     """conv7x7/2 + BN(train) + ReLU + maxpool3x3/2, incl. the padded-NHWC4 'virtual conv' trick."""
     H, W = hw
