@@ -61,11 +61,8 @@ int stem_pack_u8(const uint8_t* img_nhwc, int N, int H, int W, int Hp, int Wp, c
 template <typename T>
 int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N, int H, int W, int C,
                       T* y, uint8_t* idx, hipStream_t st);
-// dy_full[n][h][w][c] = sum over pooled windows whose argmax is (h,w) of dpool
-template <typename T>
-int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, T* dy_full, hipStream_t st);
 
-// Stem backward without the full-resolution un-pooled gradient: dz = maxpool_bwd(dpool)[n][h][w][c] * (x*scale+shift > 0) is
+// Stem backward without the full-resolution un-pooled gradient: dz = (sum of dpool over the pooling windows whose argmax is (h,w))[c] * (x*scale+shift > 0) is
 // recomputed from the pooled gradient + argmax bytes inside the BatchNorm-backward reduce and apply passes
 // (saves one 411 MB write and two reads of it at batch 256).
 template <typename T>

@@ -628,59 +628,6 @@ int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N,
   return MMSKIN_OK;
 }
 
-template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void maxpool_bwd_kernel(const T* __restrict__ dpool,
-                                                              const uint8_t* __restrict__ idx, int N, int H, int W,
-                                                              int C, int PH, int PW, T* __restrict__ dy) {
-  constexpr int EPC = DT<T>::EPC;
-  const int CPR = C / EPC;
-  const size_t total = (size_t)N * H * W * CPR;
-  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * EW_BLOCK) {
-    int cj = (int)(i % CPR);
-    size_t t = i / CPR;
-    int w = (int)(t % W); t /= W;
-    int h = (int)(t % H);
-    int n = (int)(t / H);
-    float acc[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-    for (int ph = h / 2; ph <= (h + 1) / 2; ++ph) {
-      if (ph >= PH) continue;
-      int r = h - (2 * ph - 1);
-      for (int pw = w / 2; pw <= (w + 1) / 2; ++pw) {
-        if (pw >= PW) continue;
-        int s = w - (2 * pw - 1);
-        const int tap = r * 3 + s;
-        size_t po = (((size_t)n * PH + ph) * PW + pw) * C + cj * EPC;
-        Chunk<T> g;
-        g.load(dpool + po);
-        uint32_t iw[2] = {0u, 0u};
-        if constexpr (EPC == 8) {
-          uint2 q = *reinterpret_cast<const uint2*>(idx + po);
-          iw[0] = q.x; iw[1] = q.y;
-        } else {
-          iw[0] = *reinterpret_cast<const uint32_t*>(idx + po);
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if ((int)((iw[e >> 2] >> (8 * (e & 3))) & 0xffu) == tap) acc[e] += g.v[e];
-      }
-    }
-    Chunk<T> o;
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
-    o.store(dy + i * EPC);
-  }
-}
-template <typename T>
-int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, T* dy_full, hipStream_t st) {
-  int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / DT<T>::EPC))), dim3(EW_BLOCK),
-                     0, st, dpool, idx, N, H, W, C, PH, PW, dy_full);
-  HIP_CHECK_RET(hipGetLastError());
-  return MMSKIN_OK;
-}
-
 // Stem backward works on pooled CELLS: the 2x2 input pixels (2ph..2ph+1, 2pw..2pw+1) receive gradient from the four
 // pooling windows (ph..ph+1, pw..pw+1) only, so one thread loads those four windows once (gradient + argmax bytes) and
 // the four pixels' x -- 12 independent 16-byte loads in flight instead of a dependent gather per pixel.
@@ -688,7 +635,7 @@ int maxpool_bwd(const T* dpool, const uint8_t* idx, int N, int H, int W, int C, 
 //   pixel (2ph  ,2pw+1): (ph,pw) tap 5, (ph,pw+1) tap 3
 //   pixel (2ph+1,2pw  ): (ph,pw) tap 7, (ph+1,pw) tap 1
 //   pixel (2ph+1,2pw+1): (ph,pw) tap 8, (ph,pw+1) tap 6, (ph+1,pw) tap 2, (ph+1,pw+1) tap 0      (tap = 3*r + s)
-// Sums run in ascending (ph, pw) window order, like maxpool_bwd_kernel, so both formulations give identical bits.
+// Sums run in ascending (ph, pw) window order (what a per-pixel gather over its windows does too).
 template <typename T>
 __device__ __forceinline__ void stem_cell_grad(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
                                                const float* __restrict__ scale, const float* __restrict__ shift, size_t n, int ph,
@@ -1028,7 +975,6 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
   template int stem_pack<T>(const float*, int, int, int, int, int, T*, hipStream_t);                            \
   template int stem_pack_u8<T>(const uint8_t*, int, int, int, int, int, const float*, T*, hipStream_t);        \
   template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \
-  template int maxpool_bwd<T>(const T*, const uint8_t*, int, int, int, int, T*, hipStream_t);                   \
   template int stem_pool_bn_bwd_reduce<T>(const T*, const uint8_t*, const T*, const float*, const float*, int, int, int, int, float*, int*, hipStream_t); \
   template int stem_pool_bn_bwd_apply<T>(const T*, const uint8_t*, const T*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, T*, hipStream_t); \
   template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \
