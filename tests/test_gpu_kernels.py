@@ -324,3 +324,35 @@ assert errs[0] > 1e-5      # really the bf16 path (outputs rounded to bf16), not
     r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("blocks", ["3", "7"])
+def test_wgrad3x3_multi_stage_splits(blocks):
+    """All-taps 3x3 weight gradient with few workgroups (MMSKIN_WGRAD3_BLOCKS, read once -> fresh process): every split
+    walks many stages, crosses image boundaries and -- with 7 -- starts in the middle of an image (ragged last stage:
+    14 rows = 4 + 4 + 4 + 2).  bf16 path against torch on the same inputs."""
+    import subprocess, sys
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r, %r]
+import torch, torch.nn.functional as F
+from gpu_util import DEV, conv_backward, rel_err
+g = torch.Generator().manual_seed(11)
+for (N, Cin, H, W, Cout) in [(5, 64, 14, 14, 128), (3, 128, 9, 13, 64), (2, 64, 56, 56, 64)]:
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=1, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    e = rel_err(dw, wr.grad)
+    print("ERR", (N, Cin, H, W, Cout), e)
+    assert e < 5e-2, e
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMSKIN_WGRAD3_BLOCKS=blocks)
+    r = subprocess.run([sys.executable, "-c", code % (os.path.join(root, "tests"), root,
+                                                     os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
