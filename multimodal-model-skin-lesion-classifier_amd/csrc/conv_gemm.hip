@@ -227,12 +227,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; ssb[e] = 0.f; }
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  // EPI == 2: the light epilogue (addend / bias / ReLU only: folded-BN inference, plain accumulating dgrads) -- the mask and
+  // BatchNorm-backward operands below are compile-time null, which brings the kernel back to 4 workgroups per CU
   const unsigned char* add_b = EPI ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
-  const unsigned char* my_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
-  const uint8_t* mb_b = EPI ? p.ep_mask_bits : nullptr;
-  const unsigned char* ex_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
-  const unsigned char* ex2_b = EPI ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
-  const bool mask_from_x = EPI && p.ep_scale != nullptr;
+  const unsigned char* my_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
+  const uint8_t* mb_b = EPI == 1 ? p.ep_mask_bits : nullptr;
+  const unsigned char* ex_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
+  const unsigned char* ex2_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
+  const bool mask_from_x = EPI == 1 && p.ep_scale != nullptr;
   const bool has_bias = EPI && p.ep_bias != nullptr;
   const bool do_relu = EPI && p.ep_relu;
   float ebias[EPC];
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
       }
       goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
-      if constexpr (EPI) {
-        q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+      if constexpr (EPI != 0) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+      if constexpr (EPI == 1) {
         q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
         q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
         // ep_x may be a channel prefix of a wider (concatenated) tensor: its rows are ep_x_pitch elements apart
@@ -407,14 +409,16 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   static const int nst1_min_blocks = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS"); return v ? atoi(v) : 640; }();
   static const int nst1_min_blocks_epi = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS_EPI"); return v ? atoi(v) : 800; }();   // fused-epilogue launches: 168 VGPRs = 3 workgroups/CU = 768 single-buffer slots; a 784-workgroup launch would spill into a second round
   const int bn_sel = (a.Cout % 128 == 0) ? 128 : 64;
-  const bool one = a.total_mblk * (a.Cout / bn_sel) > (epi ? nst1_min_blocks_epi : nst1_min_blocks);
+  const bool heavy_thr = a.ep_mask_y || a.ep_mask_bits || a.ep_x;
+  const bool one = a.total_mblk * (a.Cout / bn_sel) > (heavy_thr ? nst1_min_blocks_epi : nst1_min_blocks);
+  const bool heavy = a.ep_mask_y || a.ep_mask_bits || a.ep_x;   // needs the full fused epilogue (EPI = 1)
 #define GO(BNv, E) (one ? launch_cfg<T, CONV_BM, BNv, 2, 2, E, 1>(a, st) : launch_cfg<T, CONV_BM, BNv, 2, 2, E, 2>(a, st))
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
-    return epi ? GO(128, 1) : GO(128, 0);
+    return !epi ? GO(128, 0) : (heavy ? GO(128, 1) : GO(128, 2));
   }
   a.nblk_n = a.Cout / 64;
-  return epi ? GO(64, 1) : GO(64, 0);
+  return !epi ? GO(64, 0) : (heavy ? GO(64, 1) : GO(64, 2));
 #undef GO
 }
 
