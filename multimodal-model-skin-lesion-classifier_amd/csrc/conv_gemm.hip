@@ -227,16 +227,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { ssum[e] = 0.f; ssq[e] = 0.f; ssb[e] = 0.f; }
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
-  // EPI == 2: the light epilogue (addend / bias / ReLU only: folded-BN inference, plain accumulating dgrads) -- the mask and
-  // BatchNorm-backward operands below are compile-time null, which brings the kernel back to 4 workgroups per CU
-  const unsigned char* add_b = EPI ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
-  const unsigned char* my_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
-  const uint8_t* mb_b = EPI == 1 ? p.ep_mask_bits : nullptr;
-  const unsigned char* ex_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
-  const unsigned char* ex2_b = EPI == 1 ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
-  const bool mask_from_x = EPI == 1 && p.ep_scale != nullptr;
-  const bool has_bias = EPI && p.ep_bias != nullptr;
-  const bool do_relu = EPI && p.ep_relu;
+  // Epilogue profiles (compile-time null operands cost no registers; 168 VGPRs for the full set = 3 workgroups per CU):
+  //   1 everything | 2 light: addend / bias / ReLU (folded-BN inference, accumulating dgrads; 120 VGPRs = 4 per CU)
+  //   3 x (+ mask from x*scale+shift) and the BatchNorm-backward sums          (dgrads into a conv -> BN -> ReLU unit)
+  //   4 addend + 1-bit ReLU mask + x and the sums                               (dgrads into a residual block output)
+  //   5 = 4 + x2 and its sums                                                   (... whose block has a downsample BatchNorm too)
+  constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5, HAS_BR = EPI == 1 || EPI == 2, HAS_MY = EPI == 1;
+  constexpr bool HAS_MB = EPI == 1 || EPI == 4 || EPI == 5, HAS_X = EPI == 1 || EPI >= 3, HAS_X2 = EPI == 1 || EPI == 5;
+  const unsigned char* add_b = HAS_ADD ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
+  const unsigned char* my_b = HAS_MY ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
+  const uint8_t* mb_b = HAS_MB ? p.ep_mask_bits : nullptr;
+  const unsigned char* ex_b = HAS_X ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
+  const unsigned char* ex2_b = HAS_X2 ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
+  const bool mask_from_x = HAS_X && p.ep_scale != nullptr;
+  const bool has_bias = HAS_BR && p.ep_bias != nullptr;
+  const bool do_relu = HAS_BR && p.ep_relu;
   float ebias[EPC];
   if (has_bias) {
 #pragma unroll
@@ -273,15 +278,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
       }
       goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
-      if constexpr (EPI != 0) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
-      if constexpr (EPI == 1) {
-        q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
-        q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
+      if constexpr (HAS_ADD) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+      if constexpr (HAS_MY) q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
+      if constexpr (HAS_MB) q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
+      if constexpr (HAS_X) {
         // ep_x may be a channel prefix of a wider (concatenated) tensor: its rows are ep_x_pitch elements apart
         const size_t xoff = p.ep_x_pitch ? ((size_t)orow * p.ep_x_pitch + n0 + cj * EPC) * sizeof(T) : goffs[k];
         q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + xoff : zp);
-        q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
       }
+      if constexpr (HAS_X2) q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
     }
 #pragma unroll
     for (int k = 0; k < EG; ++k) {
@@ -409,16 +414,22 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   static const int nst1_min_blocks = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS"); return v ? atoi(v) : 640; }();
   static const int nst1_min_blocks_epi = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS_EPI"); return v ? atoi(v) : 800; }();   // fused-epilogue launches: 168 VGPRs = 3 workgroups/CU = 768 single-buffer slots; a 784-workgroup launch would spill into a second round
   const int bn_sel = (a.Cout % 128 == 0) ? 128 : 64;
-  const bool heavy_thr = a.ep_mask_y || a.ep_mask_bits || a.ep_x;
-  const bool one = a.total_mblk * (a.Cout / bn_sel) > (heavy_thr ? nst1_min_blocks_epi : nst1_min_blocks);
-  const bool heavy = a.ep_mask_y || a.ep_mask_bits || a.ep_x;   // needs the full fused epilogue (EPI = 1)
+  const bool heavy = a.ep_mask_y || a.ep_mask_bits || a.ep_x;   // needs a fused BatchNorm-backward epilogue
+  static const bool profiles_on = [] { const char* v = getenv("MMSKIN_CONV_EPI_PROFILES"); return !v || atoi(v) != 0; }();
+  int prof = 1;
+  if (profiles_on && heavy && !a.ep_mask_y && !a.ep_bias && !a.ep_relu) {
+    if (a.ep_x && !a.addend && !a.ep_mask_bits && !a.ep_x2) prof = 3;
+    else if (a.ep_x && a.ep_mask_bits && !a.ep_scale) prof = a.ep_x2 ? 5 : 4;
+  }
+  // only the everything-profile is a 168-VGPR kernel (768 single-buffer slots); the others have the forward kernel's residency
+  const bool one = a.total_mblk * (a.Cout / bn_sel) > ((heavy && prof == 1) ? nst1_min_blocks_epi : nst1_min_blocks);
 #define GO(BNv, E) (one ? launch_cfg<T, CONV_BM, BNv, 2, 2, E, 1>(a, st) : launch_cfg<T, CONV_BM, BNv, 2, 2, E, 2>(a, st))
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
-    return !epi ? GO(128, 0) : (heavy ? GO(128, 1) : GO(128, 2));
+    return !epi ? GO(128, 0) : (!heavy ? GO(128, 2) : (prof == 3 ? GO(128, 3) : (prof == 4 ? GO(128, 4) : (prof == 5 ? GO(128, 5) : GO(128, 1)))));
   }
   a.nblk_n = a.Cout / 64;
-  return !epi ? GO(64, 0) : (heavy ? GO(64, 1) : GO(64, 2));
+  return !epi ? GO(64, 0) : (!heavy ? GO(64, 2) : (prof == 3 ? GO(64, 3) : (prof == 4 ? GO(64, 4) : (prof == 5 ? GO(64, 5) : GO(64, 1)))));
 #undef GO
 }
 
