@@ -112,6 +112,8 @@ int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, floa
  * on NHWC buffers carved from `workspace` (>= conv2d_workspace_bytes; contents irrelevant) */
 double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
                           int iters, void* workspace, void* stream);
+double mmskin_conv2d_dgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
+                                int iters, void* workspace, void* stream);
 double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
                                 int iters, void* workspace, void* stream);
 /* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */

@@ -292,6 +292,33 @@ double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw
   return (double)ms * 1e3 / iters;
 }
 
+/* same for the data-gradient launch (no fused epilogue; stride-2 layers run as parity classes) */
+double mmskin_conv2d_dgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
+                                int iters, void* workspace, void* stream) {
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  hipStream_t st = (hipStream_t)stream;
+  Carver c(workspace);
+  size_t es = dtype == MMSKIN_BF16 ? 2 : 4;
+  unsigned char* xh = c.take<unsigned char>((size_t)N * H * W * Cin * es);
+  unsigned char* wt = c.take<unsigned char>((size_t)Cout * Cin * kh * kw * es);
+  unsigned char* yh = c.take<unsigned char>((size_t)N * s.OH() * s.OW() * Cout * es);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+  auto run = [&]() -> int {
+    if (dtype == MMSKIN_BF16) return launch_conv_dgrad<bf16_t>(s, (bf16_t*)yh, (bf16_t*)wt, (bf16_t*)xh, (const bf16_t*)nullptr, st);
+    return launch_conv_dgrad<float>(s, (float*)yh, (float*)wt, (float*)xh, (const float*)nullptr, st);
+  };
+  for (int i = 0; i < 3; ++i) if (run()) return -1.0;
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) if (run()) return -1.0;
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return (double)ms * 1e3 / iters;
+}
+
 /* same for the weight-gradient kernel (+ its slab reduction) */
 double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
                                 int iters, void* workspace, void* stream) {

@@ -475,6 +475,19 @@ int conv_dgrad_partial_rows(const ConvShape& s) {
   return ceil_div(s.N * s.H * s.W, CONV_BM) + s.stride * s.stride;
 }
 
+// Tap-less parity classes of a strided dgrad (1x1 / stride 2: three of four input pixels receive no gradient) are plain
+// zero fills.  As GEMM workgroups they cost a full prologue + row-index epilogue each (layer2's downsample dgrad: 9 408 of
+// 12 544 workgroups, 104 us of launch overhead with every load, MFMA and store ablated); here 16 B per lane, row-contiguous.
+__global__ __launch_bounds__(256) void parity_zero_fill_kernel(uint4* __restrict__ out, int H, int W, int chunks_per_pixel, int S,
+                                                               unsigned zero_mask) {
+  const int y = blockIdx.y, n = blockIdx.z;
+  const int t = blockIdx.x * 256 + threadIdx.x;          // over W * chunks_per_pixel
+  if (t >= W * chunks_per_pixel) return;
+  const int x = t / chunks_per_pixel;
+  if (!((zero_mask >> ((y % S) * S + (x % S))) & 1u)) return;
+  out[((size_t)(n * H + y) * W) * chunks_per_pixel + t] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 template <typename T>
 int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* din, const T* addend,
                       hipStream_t st, DgradFuse* fuse) {
@@ -496,10 +509,9 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   a.Sy = 1; a.Sx = 1; a.OS = s.stride;
   a.OHf = s.H; a.OWf = s.W;
   a.ncls = 0;
-  // Parity classes from the heaviest down (3x3, stride 2, pad 1: 4, 2, 2, 1 taps): the long-K workgroups start first and the
-  // short ones fill the tail of the launch instead of the other way round.
-  for (int ph = s.stride - 1; ph >= 0; --ph)
-    for (int pw = s.stride - 1; pw >= 0; --pw) {
+  unsigned zero_mask = 0;   // parity classes (ph * stride + pw) without taps that only need zeros
+  for (int ph = 0; ph < s.stride; ++ph)
+    for (int pw = 0; pw < s.stride; ++pw) {
       TapClass c = {};
       c.a_dim = (s.H - ph + s.stride - 1) / s.stride;
       c.b_dim = (s.W - pw + s.stride - 1) / s.stride;
@@ -517,8 +529,21 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
       if (c.a_dim <= 0 || c.b_dim <= 0) continue;
       // a tap-less class contributes zeros: skip it when accumulating in place
       if (c.ntaps == 0 && addend == din && addend != nullptr) continue;
+      static const bool zf = [] { const char* v = getenv("MMSKIN_DGRAD_ZEROFILL"); return !v || atoi(v) != 0; }();
+      if (zf && c.ntaps == 0 && addend == nullptr && !fuse) { zero_mask |= 1u << (ph * s.stride + pw); continue; }   // plain zero fill
       a.cls[a.ncls++] = c;
     }
+  if (zero_mask) {
+    const int cpp = s.Cin * (int)sizeof(T) / 16;
+    ARG_CHECK(s.H <= 65535 && s.N <= 65535 && (s.Cin * sizeof(T)) % 16 == 0, "conv_dgrad: zero fill grid");
+    hipLaunchKernelGGL(parity_zero_fill_kernel, dim3(ceil_div(s.W * cpp, 256), s.H, s.N), dim3(256), 0, st,
+                       reinterpret_cast<uint4*>(din), s.H, s.W, cpp, s.stride, zero_mask);
+    HIP_CHECK_RET(hipGetLastError());
+  }
+  // Parity classes from the heaviest down (3x3 / stride 2 / pad 1: 4, 2, 2, 1 taps; 1x1 / stride 2: 1, 0, 0, 0): the long-K
+  // workgroups start first and the short ones fill the tail of the launch instead of the other way round.
+  for (int i = 1; i < a.ncls; ++i)
+    for (int j = i; j > 0 && a.cls[j].ntaps > a.cls[j - 1].ntaps; --j) { TapClass t = a.cls[j]; a.cls[j] = a.cls[j - 1]; a.cls[j - 1] = t; }
   finish_classes(a);
   if (fuse) fuse->rows_written = a.total_mblk;
   return dispatch_conv_gemm<T>(a, st);

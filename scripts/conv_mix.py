@@ -1,4 +1,4 @@
-"""GPU box: time every distinct ResNet-50 conv shape (batch 256) and print the count-weighted total (MMSKIN_MIX_OP=fwd|wgrad).
+"""GPU box: time every distinct ResNet-50 conv shape (batch 256) and print the count-weighted total (MMSKIN_MIX_OP=fwd|dgrad|wgrad).
 Usage: python scripts/conv_mix.py [label]   (kernel variants are selected through MMSKIN_* env vars)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,7 +32,7 @@ for name, cnt, Cin, H, Cout, k, s in SHAPES:
     p = k // 2
     OH = (H + 2 * p - k) // s + 1
     fl = 2.0 * N * OH * OH * Cout * Cin * k * k
-    fn = lib.mmskin_conv2d_wgrad_time if os.environ.get("MMSKIN_MIX_OP") == "wgrad" else lib.mmskin_conv2d_time
+    fn = {"wgrad": lib.mmskin_conv2d_wgrad_time, "dgrad": lib.mmskin_conv2d_dgrad_time}.get(os.environ.get("MMSKIN_MIX_OP"), lib.mmskin_conv2d_time)
     us = fn(N, Cin, H, H, Cout, k, k, s, p, _lib.BF16, 20, ptr(ws), stream())
     rows.append(f"{name:22s} x{cnt}  {us:8.1f} us  {fl / us / 1e6:6.0f} TF/s")
     tot += cnt * us; totf += cnt * fl
