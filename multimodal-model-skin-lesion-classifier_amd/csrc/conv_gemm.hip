@@ -36,7 +36,7 @@ template <> struct Mma<float> {
   }
 };
 
-#define TAP_LDS_BYTES 256
+#define TAP_LDS_BYTES 768   // tap table (3 x 16 ints) + output-row table of strided / multi-class launches (128 ints)
 
 // 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
 __device__ uint4 g_zero_page[16];
@@ -202,6 +202,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 
   if (abl & 16) return;   // timing experiments only
   // ---- epilogue: acc -> LDS [pixel][channel] (packed) -> coalesced 16-byte stores
+  // Strided dgrad classes scatter their rows over the full-resolution output: one thread per tile row works out its
+  // destination row (two integer divisions) once, instead of every thread doing it for each of its 8 rows.
+  const bool simple_rows = (p.OS == 1 && p.ncls == 1);
+  int* s_orow = s_tap + 64;
+  if (!simple_rows && tid < BM) {
+    const int m = m0 + tid;
+    const int mm = m < rows ? m : m0;
+    const int img = mm / ab, rem = mm - img * ab;
+    const int a = rem / b_dim, b = rem - a * b_dim;
+    s_orow[tid] = (img * p.OHf + a * p.OS + p.cls[ci].ph) * p.OWf + b * p.OS + p.cls[ci].pw;
+  }
   unsigned char* Cs = smem + TAP_LDS_BYTES;
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -252,8 +263,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { esc[e] = p.ep_scale[n0 + cj * EPC + e]; esh[e] = p.ep_shift[n0 + cj * EPC + e]; }
   }
-  const bool simple_rows = (p.OS == 1 && p.ncls == 1);
-  const int ph = p.cls[ci].ph, pw = p.cls[ci].pw;
   // Rows are handled in groups of EG: all global reads of a group (addend, mask source, BN inputs) are
   // issued before any of them is consumed, so EG*3 16-byte loads are in flight per lane instead of one
   // dependent load->store chain per row (the fused epilogue was running at ~3 TB/s that way).
@@ -271,12 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
       const int row = r0 + (grp + k) * ROWS_PER_PASS;
       const int m = m0 + row;
       valid[k] = m < rows;
-      int orow = valid[k] ? m : m0;
-      if (!simple_rows) {
-        int img = orow / ab, rem = orow - img * ab;
-        int a = rem / b_dim, b = rem - a * b_dim;
-        orow = (img * p.OHf + a * p.OS + ph) * p.OWf + b * p.OS + pw;
-      }
+      const int orow = simple_rows ? (valid[k] ? m : m0) : s_orow[row];
       goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
       if constexpr (HAS_ADD) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
       if constexpr (HAS_MY) q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
