@@ -36,7 +36,7 @@ template <> struct Mma<float> {
   }
 };
 
-#define TAP_LDS_BYTES 768   // tap table (3 x 16 ints) + output-row table of strided / multi-class launches (128 ints)
+#define TAP_LDS_BYTES 2304   // tap table (3 x 16 ints) | output-row table of strided / multi-class launches (128 ints) | source-row table (3 x 128 ints)
 
 // 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
 __device__ uint4 g_zero_page[16];
@@ -87,26 +87,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
     s_tap[16 + tid] = (oy & 0xffff) | (ox << 16);
     s_tap[32 + tid] = wt * C;
   }
+  // source pixel of every tile row: (image, y, x) costs two integer divisions -- one thread per ROW does them, not every
+  // thread for each of its rows (eight threads share a row; the divisions were most of a short-K workgroup's prologue)
+  const int ab = a_dim * b_dim;
+  int* s_src = s_tap + 192;   // [3][BM]: base offset, y, x
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int base = 0, iy = -(1 << 20), ix = -(1 << 20);
+    if (m < rows) {
+      const int img = m / ab, rem = m - img * ab;
+      const int a = rem / b_dim, b = rem - a * b_dim;
+      iy = a * p.Sy;
+      ix = b * p.Sx;
+      base = ((img * IH + iy) * IW + ix) * p.Cpitch;
+    }
+    s_src[tid] = base; s_src[BM + tid] = iy; s_src[2 * BM + tid] = ix;
+  }
   __syncthreads();
 
   // ---- loader state: this thread moves chunk column jc of rows lr + 32*i
   const int lr = tid >> 3, jc = tid & 7;
   int a_base[AP], a_iy[AP], a_ix[AP];
-  const int ab = a_dim * b_dim;
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    int m = m0 + lr + 32 * i;
-    if (m < rows) {
-      int img = m / ab, rem = m - img * ab;
-      int a = rem / b_dim, b = rem - a * b_dim;
-      a_iy[i] = a * p.Sy;
-      a_ix[i] = b * p.Sx;
-      a_base[i] = ((img * IH + a_iy[i]) * IW + a_ix[i]) * p.Cpitch;
-    } else {
-      a_iy[i] = -(1 << 20);
-      a_ix[i] = -(1 << 20);
-      a_base[i] = 0;
-    }
+    const int r = lr + 32 * i;
+    a_base[i] = s_src[r]; a_iy[i] = s_src[BM + r]; a_ix[i] = s_src[2 * BM + r];
   }
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
   const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w) +
