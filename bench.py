@@ -5,6 +5,7 @@ fusion, batch 256 per GPU, bf16 backbone compute, synthetic 224x224x3 images + 2
 (BASELINE.json configs[1]).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: spawns its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -15,8 +16,11 @@ bounded sample of the same workload.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -82,6 +86,103 @@ WORKLOADS = {
 }
 
 
+def source_hash():
+    """Identity of the kernel sources the loaded library was built from (the GPU box has no .git): sha256 over csrc/."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def active_knobs():
+    """Every MMSKIN_* environment variable in effect: part of `config`, so a tuned or experimental run is visible as one."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("MMSKIN_")}
+
+
+def refuse_work_skipping():
+    """The production library has the ablation switches compiled out (`make ablate` builds a separate one for scripts/);
+    a benchmark run must not even be asked to skip work."""
+    bad = [k for k in os.environ if k.startswith("MMSKIN_") and "ABLATE" in k]
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with work-skipping switches set: {bad}")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start N fresh rank processes of this same
+    script BEFORE this process touches the GPU, relay rank 0's JSON line, fail if any rank fails."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py: rank exit codes {codes}")
+
+
+def rehearse(args, rank, world):
+    """Everything of main() that is not the HIP path, on CPU over gloo (see --rehearse)."""
+    import torch.distributed as dist
+    from mmskin import dp
+    if world > 1:
+        dist.init_process_group("gloo")
+    torch.manual_seed(rank)
+    model = nn.Sequential(nn.Linear(20, 32), nn.ReLU(), nn.Linear(32, 6))
+    if world > 1:
+        dp.broadcast_parameters(model)
+    g = torch.Generator().manual_seed(1234 + rank)
+    x, y = torch.randn(16, 20, generator=g), torch.randint(0, 6, (16,), generator=g)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        if world > 1:
+            dp.allreduce_gradients(model, world)
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    w0 = model[0].weight.detach().clone()
+    same = True
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+        ref = w0.clone()
+        dist.broadcast(ref, 0)
+        ok = torch.tensor([float(torch.equal(ref, w0))])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        same = bool(ok.item())
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL: launcher / collective plumbing only, no HIP path", "value": None, "unit": None,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "data": "rehearsal", "ranks_in_sync": same}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not same:
+        raise SystemExit("rehearsal: ranks diverged")
+
+
 def make_meta(workload, batch, generator):
     if workload in ("densenet169-metablock", "davit-tiny-gfcam"):   # 82 categorical codes (cardinality 10) + 4 continuous columns
         cat = torch.randint(0, 10, (batch, 82), generator=generator).float()
@@ -142,13 +243,23 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force every rank onto this device (rehearsal on a 1-GPU box)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU plumbing check of the multi-rank entry (tests/test_cpu_dp.py): launcher, rendezvous, gradient "
+                         "all-reduce, max-over-ranks timing and the JSON line, with a toy torch model over gloo -- no HIP "
+                         "path, no benchmark number")
     args = ap.parse_args()
+    knobs = active_knobs()
 
+    refuse_work_skipping()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        return rehearse(args, rank, world)
     dev_index = local_rank if args.device is None else args.device
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
@@ -249,15 +360,21 @@ def main():
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         dom_by = (by[0] + by[1]) / nprof
-        traffic = None
-        try:   # per-launch HBM bytes from the committed PMC pass (FETCH_SIZE x2 + WRITE_SIZE, see profiles/)
+        # per-launch HBM bytes from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, scripts/pmc_traffic.py); only
+        # quoted when they were taken on exactly these kernel sources, else null
+        traffic, traffic_note = None, "no PMC pass committed"
+        try:
             with open(os.path.join(ROOT, "profiles", "conv_gemm_traffic.json")) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                tj = json.load(f)
+            if tj.get("source_hash") == source_hash():
+                traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "PMC pass on this build (profiles/conv_gemm_traffic.json)"
+            else:
+                traffic_note = f"committed PMC pass is for sources {tj.get('source_hash')}, this build is {source_hash()}"
         except OSError:
             pass
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": traffic, "launches_per_step": int(n_launch),
+                    "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n_launch),
                     "algorithmic_gbytes_per_launch": round(dom_by / max(n_launch, 1) / 1e9, 4),
                     "algorithmic_gbps": round(dom_by / (dom_ms * 1e-3) / 1e9, 1),
                     "hbm_floor_ms": round(dom_by / 6.3e12 * 1e3, 3), "mfma_floor_ms": round(dom_fl / (peak * 1e12) * 1e3, 3),
@@ -278,14 +395,15 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl["label"],
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "weights": "random init (torchvision layout)", "unfreeze_weights": "unfrozen_weights"},
+                       "weights": "random init (torchvision layout)", "unfreeze_weights": "unfrozen_weights",
+                       "knobs": knobs, "source_hash": source_hash()},
             "step_tflops_per_gpu": round(ips / world * wl["flop_per_image"] / 1e12, 1),
             "step_frac_of_peak": round(ips / world * wl["flop_per_image"] / 1e12 / peak, 4),
             "loss": round(loss_val, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline and not args.infer:
-            out["cpu_baseline"] = cpu_baseline(32, workload=args.workload)
+            out["cpu_baseline"] = cpu_baseline(32, workload=args.workload)   # batches of 32, not 256: bounded sample
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

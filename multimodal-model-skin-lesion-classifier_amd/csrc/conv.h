@@ -49,7 +49,7 @@ struct ConvGemmArgs {
   int Sy, Sx, OS;
   int OHf, OWf;
   int ncls, total_mblk, nblk_n;
-  int ablate;          // debug/timing only: bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores
+  int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
   TapClass cls[4];
 };
 
@@ -68,10 +68,6 @@ struct WgradArgs {
   int ablate;          // timing experiments only: bit0 skip X loads, bit1 skip Y loads, bit2 skip MFMA+LDS reads, bit3 skip slab store, bit4 skip LDS writes
   int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
 };
-
-// pipelined production kernel (conv_pipe.hip); fills a.nblk_n
-template <typename T>
-int launch_conv_pipe(ConvGemmArgs& a, hipStream_t st);
 
 // Inference epilogue (eval-mode BatchNorm folded into the conv): out = [relu](acc + bias[c] + addend)
 struct FwdFuse {

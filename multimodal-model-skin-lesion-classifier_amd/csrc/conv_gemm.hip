@@ -127,7 +127,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const int nk = ntaps * C / BK;
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_zero_page);
   const int wid_u = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform
-  const int abl = p.ablate;                                     // timing experiments only (0 in production)
+#ifdef MMSKIN_ABLATE   // `make ablate` (scripts/ only): the production library has no work-skipping switch
+  const int abl = p.ablate;
+#else
+  constexpr int abl = 0;
+#endif
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 // The DMA is issued from inline asm: through the builtin, hipcc models it as an LDS store that may alias
@@ -408,14 +412,10 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   for (int i = 0; i < a.ncls; ++i)
     ARG_CHECK((a.cls[i].ntaps * a.C) % DT<T>::BK == 0, "conv_gemm: K=%d not a multiple of %d",
               a.cls[i].ntaps * a.C, DT<T>::BK);
-  // MMSKIN_CONV_VARIANT=pipe selects the 8-wave / 3-stage kernel of conv_pipe.hip (A/B timing: it is
-  // ~15 % slower than this file's 4-wave, 2 workgroups-per-CU kernel on every ResNet-50 layer shape --
-  // profiles/r01_c_conv_ablation.txt); the default is the kernel of this file.
-  const char* var = getenv("MMSKIN_CONV_VARIANT");
-  const bool simple = !(var && !strcmp(var, "pipe"));
-  const char* abl = getenv("MMSKIN_CONV_ABLATE");   // timing experiments only
-  a.ablate = abl ? atoi(abl) : 0;
-  if (!simple && !a.ep_x && !a.ep_bias && !a.ep_relu) return launch_conv_pipe<T>(a, st);   // the pipe variant has no fused BN-bwd epilogue
+  a.ablate = 0;
+#ifdef MMSKIN_ABLATE
+  { const char* abl = getenv("MMSKIN_CONV_ABLATE"); a.ablate = abl ? atoi(abl) : 0; }
+#endif
   const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer

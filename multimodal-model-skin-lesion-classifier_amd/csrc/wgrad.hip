@@ -152,7 +152,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   const u32x4_t z4 = {0, 0, 0, 0};
   u32x4_t rxA0 = z4, rxA1 = z4, rxA2 = z4, rxA3 = z4, ryA0 = z4, ryA1 = z4, ryA2 = z4, ryA3 = z4;
   u32x4_t rxB0 = z4, rxB1 = z4, rxB2 = z4, rxB3 = z4, ryB0 = z4, ryB1 = z4, ryB2 = z4, ryB3 = z4;
+#ifdef MMSKIN_ABLATE   // `make ablate` (scripts/ only)
   const int abl = p.ablate;
+#else
+  constexpr int abl = 0;
+#endif
   int m_stage = m_begin;  // first row of the stage the next LOAD_STAGE() fetches
   const unsigned char* zero_page = reinterpret_cast<const unsigned char*>(g_wzero_page);
   const int OWr = p.OW, OHr = p.OH;
@@ -419,7 +423,10 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   ARG_CHECK(a.OW <= 240 && a.OH <= 240, "wgrad: output %dx%d too large for the 16-bit reciprocal pixel stepping", a.OH, a.OW);
   int BO, BKK;
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split, a.ntaps);
+  a.ablate = 0;
+#ifdef MMSKIN_ABLATE
   { const char* v = getenv("MMSKIN_WGRAD_ABLATE"); a.ablate = v ? atoi(v) : 0; }
+#endif
   int rc;
   if (BO == 256) rc = launch_wg<T, 256, 128, 1>(a, st);
   else if (BO == 128 && BKK == 128) rc = launch_wg<T, 128, 128, 2>(a, st);

@@ -124,8 +124,14 @@ class _BackboneFn(torch.autograd.Function):
         # plan reuses the BN-folded staged weights already in the workspace (tensor version counters; a training forward
         # updates the running statistics behind torch's back, so it always invalidates)
         # (Parameters alias the flat arena through .data, which does not share its version counter: sum the parameters' own --
-        # counters only grow, so the sum changes whenever any of them does.)
-        key = None if training else (sum(p._version for p in params), module._flat_b._version, module._flat_p.data_ptr())
+        # counters only grow, so the sum changes whenever any of them does.)  The C call updates running_mean / running_var
+        # without touching any version counter, so every training forward -- on ANY plan of this module -- bumps
+        # module._stats_gen, which is part of the key: an eval plan of another batch shape never reuses weights folded
+        # with the previous epoch's statistics.
+        if training:
+            module._stats_gen += 1
+        key = None if training else (sum(p._version for p in params), module._flat_b._version, module._flat_p.data_ptr(),
+                                     module._stats_gen)
         call("mmskin_backbone_set_option", plan.handle, b"reuse_staged", int(key is not None and plan.eval_key == key))
         plan.eval_key = key
         if u8:
@@ -199,6 +205,7 @@ class _FlatBackbone(nn.Module):
     # Normalisation applied to uint8 NHWC inputs (skinLesionDatasets.py:29: ImageNet mean / std on the 0..1 scale)
     input_mean = (0.485, 0.456, 0.406)
     input_std = (0.229, 0.224, 0.225)
+    max_plans = 4
 
     def _init_flat(self, compute_dtype):
         self.compute_dtype = (compute_dtype or default_compute_dtype()).lower()
@@ -209,6 +216,7 @@ class _FlatBackbone(nn.Module):
         self._flat_b = None
         self._layout = None
         self.last_flat_grad = None
+        self._stats_gen = 0      # training forwards so far (they rewrite the BatchNorm running statistics in place)
         self._repack()
 
     # ------------------------------------------------------------------ flat parameter arena
@@ -264,6 +272,8 @@ class _FlatBackbone(nn.Module):
     def _plan_for(self, N, H, W, device):
         key = (N, H, W, self.compute_dtype, str(device))
         plan = self._plans.get(key)
+        if plan is not None:
+            self._plans[key] = self._plans.pop(key)   # most recently used last
         if plan is None:
             plan = _Plan(self.arch, N, H, W, _DTYPES[self.compute_dtype], device)
             table = plan.tensor_table(0)
@@ -275,7 +285,9 @@ class _FlatBackbone(nn.Module):
             bmine = [f"{n}.{k}" for n, _ in self._bn_buffers() for k in ("running_mean", "running_var")]
             if [t[0] for t in btable] != bmine:
                 raise _lib.MMSkinError(f"{type(self).__name__} buffer layout disagrees with the C plan")
-            if len(self._plans) >= 2:   # keep at most two shapes alive (train + ragged last batch)
+            # the reference loop produces three shapes per epoch (full batch, ragged last train batch, ragged last
+            # validation batch; train_pad_20.py:105,121) plus the evaluation passes: keep four plans, drop the oldest
+            if len(self._plans) >= self.max_plans:
                 self._plans.pop(next(iter(self._plans)))
             self._plans[key] = plan
         return plan

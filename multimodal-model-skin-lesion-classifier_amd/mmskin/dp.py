@@ -163,10 +163,31 @@ class OverlappedGradSync:
         return nbytes
 
 
-def shard_indices(n, rank, world_size, epoch_seed=0):
-    """Rank-sharded random permutation of range(n) (replaces the single-process sampler,
-    train_pad_20.py:298-302, under DP): every rank draws the same permutation and keeps its slice."""
-    g = torch.Generator().manual_seed(epoch_seed)
-    perm = torch.randperm(n, generator=g)
-    per = n // world_size
-    return perm[rank * per:(rank + 1) * per]
+def shard_indices(n, rank, world_size, epoch_seed=0, weights=None, num_samples=None):
+    """This rank's share of one epoch's sample indices (replaces the single-process sampler of
+    train_pad_20.py:297-302 under DP).  Every rank makes the SAME seeded draw and keeps a strided slice of it, so
+    the union over ranks is exactly the single-process draw.
+
+    weights given (the reference's case: `WeightedRandomSampler(sample_weights, num_samples=len(sample_weights),
+    replacement=True)`, class-balanced, train_pad_20.py:290-302): `torch.multinomial(weights, num_samples,
+    replacement=True)` -- the call WeightedRandomSampler itself makes -- so indices repeat and rare classes are drawn as
+    often as on one GPU.  weights None: a uniform permutation without replacement.
+
+    The draw is padded by wrapping around (as torch's DistributedSampler does) so that every rank gets
+    ceil(num_samples / world_size) indices and no sample of the draw is dropped: the per-rank batch counts stay
+    equal, which the per-step gradient all-reduce needs."""
+    g = torch.Generator().manual_seed(int(epoch_seed))
+    if weights is not None:
+        w = torch.as_tensor(weights, dtype=torch.double)
+        total = int(num_samples) if num_samples is not None else w.numel()
+        draw = torch.multinomial(w, total, replacement=True, generator=g)
+    else:
+        draw = torch.randperm(n, generator=g)
+        if num_samples is not None:
+            draw = draw[:int(num_samples)]
+    total = draw.numel()
+    per = -(-total // world_size)
+    pad = per * world_size - total
+    if pad:
+        draw = torch.cat([draw, draw[:pad]])
+    return draw[rank::world_size]

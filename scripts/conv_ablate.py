@@ -1,10 +1,13 @@
-"""GPU box: time single conv layers under kernel variants / ablations (MMSKIN_CONV_VARIANT, MMSKIN_CONV_ABLATE)."""
+"""GPU box: time single conv layers under ablations (MMSKIN_CONV_ABLATE).  Needs the timing-experiment library
+(`make -C multimodal-model-skin-lesion-classifier_amd/csrc ablate` -> build_ab/libmmskin_hip_ablate.so): the production
+library has the work-skipping switches compiled out."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "multimodal-model-skin-lesion-classifier_amd")]
 import torch
 from mmskin import _lib
 from mmskin._lib import ptr, stream
+_lib.LIB_PATH = os.path.join(ROOT, "build_ab", "libmmskin_hip_ablate.so")
 lib = _lib.load()
 LAYERS = {  # name: (N, Cin, H, W, Cout, k, stride, pad)
     "l1.c2 3x3 64->64 @56": (256, 64, 56, 56, 64, 3, 1, 1),
@@ -27,7 +30,6 @@ for name, (N, Cin, H, W, Cout, k, s, p) in LAYERS.items():
     flops = 2.0 * N * OH * OH * Cout * Cin * k * k
     row = f"{name:26s}"
     for var, abl in configs:
-        os.environ["MMSKIN_CONV_VARIANT"] = var
         os.environ["MMSKIN_CONV_ABLATE"] = str(abl)
         us = lib.mmskin_conv2d_time(N, Cin, H, W, Cout, k, k, s, p, _lib.BF16, 20, ptr(ws), stream())
         row += f"{us:10.1f}"

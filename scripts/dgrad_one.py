@@ -5,6 +5,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "multimodal-model-skin-lesion-classifie
 import torch
 from mmskin import _lib
 from mmskin._lib import ptr, stream
+if os.environ.get("MMSKIN_CONV_ABLATE") or os.environ.get("MMSKIN_WGRAD_ABLATE"):   # `make ablate` library only
+    _lib.LIB_PATH = os.path.join(ROOT, "build_ab", "libmmskin_hip_ablate.so")
 lib = _lib.load()
 Cin, H, Cout, k, s = (int(v) for v in sys.argv[1:6])
 N = 256

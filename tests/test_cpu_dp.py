@@ -177,6 +177,52 @@ def test_overlapped_grad_sync_matches_plain_allreduce():
 
 
 def test_shard_indices_partition():
+    """uniform path: the ranks' slices partition the (wrap-padded) permutation; nothing of range(n) is dropped"""
     a, b = dp.shard_indices(101, 0, 2, epoch_seed=3), dp.shard_indices(101, 1, 2, epoch_seed=3)
-    assert len(a) == len(b) == 50 and not set(a.tolist()) & set(b.tolist())
+    assert len(a) == len(b) == 51
+    assert set(a.tolist()) | set(b.tolist()) == set(range(101))
+    assert len(set(a.tolist()) & set(b.tolist())) == 1            # the one wrap-around pad index
     assert not torch.equal(a, dp.shard_indices(101, 0, 2, epoch_seed=4))
+
+
+def test_shard_indices_weighted_matches_single_process_sampler():
+    """weighted path = the reference's WeightedRandomSampler(sample_weights, n, replacement=True)
+    (train_pad_20.py:290-302): the union over ranks is the single-process draw, classes come out balanced"""
+    from torch.utils.data import WeightedRandomSampler
+    labels = torch.tensor([0] * 90 + [1] * 9 + [2] * 4)            # imbalanced, n = 103 (not a multiple of 4)
+    class_w = 1.0 / torch.bincount(labels).double()
+    w = class_w[labels]
+    n, world = len(labels), 4
+    parts = [dp.shard_indices(n, r, world, epoch_seed=7, weights=w) for r in range(world)]
+    assert all(len(p) == 26 for p in parts)                        # ceil(103 / 4): equal step counts on every rank
+    merged = torch.stack(parts, dim=1).reshape(-1)                 # undo the strided slicing
+    g = torch.Generator().manual_seed(7)
+    single = torch.tensor(list(WeightedRandomSampler(w, n, replacement=True, generator=g)))
+    assert torch.equal(merged[:n], single)                         # same draw as the single-process sampler
+    assert torch.equal(merged[n:], single[:world * 26 - n])        # padding wraps around
+    assert len(set(single.tolist())) < n                           # with replacement: indices repeat
+    big = torch.cat([dp.shard_indices(n, r, world, epoch_seed=11, weights=w, num_samples=6000) for r in range(world)])
+    frac = torch.bincount(labels[big], minlength=3).double() / big.numel()
+    assert (frac - 1 / 3).abs().max() < 0.04                       # class-balanced, unlike a uniform permutation
+
+
+def test_bench_entry_self_launches_two_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run must spawn its own rank processes: the
+    2-rank gloo rehearsal of exactly that entry -- launcher, rendezvous on 127.0.0.1, gradient all-reduce, max-over-ranks
+    timing, ONE JSON line from rank 0, non-zero exit if a rank fails."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["ranks_in_sync"] is True and d["data"] == "rehearsal"
+    # work-skipping switches are refused outright
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rehearse"],
+                         env=dict(env, MMSKIN_CONV_ABLATE="4"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "work-skipping" in bad.stderr

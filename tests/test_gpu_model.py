@@ -351,3 +351,19 @@ def test_eval_forward_reuses_staged_weights_only_while_unchanged():
         fresh.load_state_dict(enc.state_dict())
         assert rel_err(d, fresh(x)) < 1e-5
         assert rel_err(d, c) > 1e-4
+    # Two plans: eval at batch 4, a training forward at batch 6 WITHOUT an optimizer step (frozen-weights mode:
+    # only the running statistics move, inside the C call, no version counter changes), eval at batch 4 again.  The
+    # batch-4 plan must notice and refold; and four shapes must coexist in the plan cache without a rebuild.
+    x6 = torch.randn(6, 3, 64, 64, device=DEV)
+    plan4 = enc._plan_for(4, 64, 64, x.device)
+    enc.train()
+    with torch.no_grad():
+        enc(x6)
+    enc.eval()
+    with torch.no_grad():
+        e = enc(x).clone()
+        fresh.load_state_dict(enc.state_dict())
+        assert rel_err(e, fresh(x)) < 1e-5
+        assert rel_err(e, d) > 1e-5                                   # the statistics did move
+        enc(torch.randn(3, 3, 64, 64, device=DEV)); enc(torch.randn(5, 3, 64, 64, device=DEV))
+    assert enc._plan_for(4, 64, 64, x.device) is plan4 and len(enc._plans) == 4
