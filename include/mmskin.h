@@ -218,6 +218,21 @@ int mmskin_embedding_backward(const float* dout, const int64_t* ids, float* dtab
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input side of the path: what the reference's Dataset does on the host before `model(image, metadata)`.
+ * resize_u8: the val/test transform's A.Resize(h, w) (skinLesionDatasets.py:116-120 = cv2.resize INTER_LINEAR on the
+ * decoded uint8 HWC image): [N][src_h][src_w][3] -> [N][dst_h][dst_w][3], uint8; Normalize + ToTensor then run inside
+ * mmskin_backbone_forward_u8.
+ * metadata_encode: OneHotEncoder(handle_unknown='ignore') + StandardScaler transform (skinLesionDatasets.py:133-183):
+ * codes int32 [batch][n_cat] = index of the value among the column's fitted (sorted) categories, -1 = unseen;
+ * col_offset int32 [n_cat + 1] = first one-hot slot of every column (col_offset[n_cat] = onehot_width); numeric fp32
+ * [batch][n_num] (NaN = missing -> nan_fill, the reference's fillna(-1)); out fp32 [batch][onehot_width + n_num] =
+ * one-hot blocks | (numeric - mean) / scale -- the tensor the reference hands to text_fc. */
+int mmskin_resize_u8(const uint8_t* src_nhwc, int N, int src_h, int src_w, uint8_t* dst_nhwc, int dst_h, int dst_w,
+                     void* stream);
+int mmskin_metadata_encode(const int32_t* codes, int n_cat, const int32_t* col_offset, int onehot_width, const float* numeric,
+                           int n_num, const float* mean, const float* scale, float nan_fill, float* out, int batch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * `custom-cnn` image encoder pieces (loadImageModelClassifier.py:50-60): small direct kernels for
  * shapes the MFMA implicit GEMM does not cover (Cin=3, Cout=16).  NCHW fp32. */
 int mmskin_direct_conv2d_forward(const float* x, const float* w, const float* b, float* y, int N, int Cin, int H, int W,

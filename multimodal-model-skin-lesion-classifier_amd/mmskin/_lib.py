@@ -100,6 +100,8 @@ _SIGNATURES = {
     "mmskin_embedding_backward": (_i, [_P] * 3 + [_i] * 4 + [_P]),
     "mmskin_direct_conv2d_forward": (_i, [_P] * 4 + [_i] * 10 + [_P]),
     "mmskin_direct_conv2d_backward": (_i, [_P] * 5 + [_i] * 9 + [_P]),
+    "mmskin_resize_u8": (_i, [_P, _i, _i, _i, _P, _i, _i, _P]),
+    "mmskin_metadata_encode": (_i, [_P, _i, _P, _i, _P, _i, _P, _P, _f, _P, _i, _P]),
     "mmskin_pool_gap_forward": (_i, [_P] * 3 + [_i] * 5 + [_P]),
     "mmskin_pool_gap_backward": (_i, [_P] * 3 + [_i] * 5 + [_P]),
 }

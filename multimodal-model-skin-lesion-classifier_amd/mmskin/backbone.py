@@ -188,14 +188,32 @@ class _CamTailFn(torch.autograd.Function):
         return feats.clone()
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dfeat):
         plan = ctx.plan
-        dfeat = dfeat.float().contiguous()
-        c, oh, ow = plan.last_conv_shape()
-        dx = torch.empty((dfeat.shape[0], c, oh, ow), device=dfeat.device, dtype=torch.float32)
-        call("mmskin_backbone_last_conv_grad", plan.handle, ptr(dfeat), ptr(plan.workspace), ptr(dx), stream())
+        with torch.no_grad():
+            d = dfeat.detach().float().contiguous()
+            c, oh, ow = plan.last_conv_shape()
+            dx = torch.empty((d.shape[0], c, oh, ow), device=d.device, dtype=torch.float32)
+            call("mmskin_backbone_last_conv_grad", plan.handle, ptr(d), ptr(plan.workspace), ptr(dx), stream())
+        if torch.is_grad_enabled() and dfeat.requires_grad:
+            # create_graph=True (cam.py:38-43): the FIRST-order gradient above is what Grad-CAM++ uses (it squares and cubes
+            # it elementwise).  Differentiating THROUGH it a second time is not implemented on the HIP path: say so.
+            dx = _NoSecondOrder.apply(dx, dfeat)
         return dx, None, None
+
+
+class _NoSecondOrder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dx, dfeat):
+        return dx.view_as(dx)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise _lib.MMSkinError(
+            "second-order differentiation through the image encoder's Grad-CAM tail is not supported on the HIP path "
+            "(ResNet plans compute d(features)/d(last conv output) in one kernel); the first-order gradients of "
+            "autograd.grad(..., create_graph=True) are exact.  DenseNet encoders hooked at features[-1] run their tail in "
+            "torch ops and do support it.")
 
 
 class _FlatBackbone(nn.Module):
@@ -206,6 +224,9 @@ class _FlatBackbone(nn.Module):
     input_mean = (0.485, 0.456, 0.406)
     input_std = (0.229, 0.224, 0.225)
     max_plans = 4
+    # (H, W) or None.  When set, uint8 NHWC batches of another size go through the GPU A.Resize kernel first (the val / test
+    # transform of skinLesionDatasets.py:116-120: Resize -> Normalize -> ToTensor, all on the device)
+    resize_to = None
 
     def _init_flat(self, compute_dtype):
         self.compute_dtype = (compute_dtype or default_compute_dtype()).lower()
@@ -269,20 +290,24 @@ class _FlatBackbone(nn.Module):
         self._repack()
         return out
 
-    def _plan_for(self, N, H, W, device):
-        key = (N, H, W, self.compute_dtype, str(device))
+    def _plan_for(self, N, H, W, device, arch=None):
+        arch = arch or getattr(self, "_arch_override", None) or self.arch
+        key = (N, H, W, self.compute_dtype, str(device), arch)
         plan = self._plans.get(key)
         if plan is not None:
             self._plans[key] = self._plans.pop(key)   # most recently used last
         if plan is None:
-            plan = _Plan(self.arch, N, H, W, _DTYPES[self.compute_dtype], device)
+            plan = _Plan(arch, N, H, W, _DTYPES[self.compute_dtype], device)
             table = plan.tensor_table(0)
-            mine = [(n, off, numel, shape) for (n, _), (off, numel, shape) in
+            # a "<arch>-features" plan run on the full model's arena (Grad-CAM on DenseNet) names tensors without the prefix
+            strip = "features." if arch != self.arch and arch.endswith("-features") else ""
+            mine = [(n[len(strip):] if strip and n.startswith(strip) else n, off, numel, shape) for (n, _), (off, numel, shape) in
                     zip(self.named_parameters(), self._layout)]
             if [(t[0], t[1], t[2]) for t in table] != [(t[0], t[1], t[2]) for t in mine]:
                 raise _lib.MMSkinError(f"{type(self).__name__} parameter layout disagrees with the C plan")
             btable = plan.tensor_table(1)
-            bmine = [f"{n}.{k}" for n, _ in self._bn_buffers() for k in ("running_mean", "running_var")]
+            bmine = [f"{n[len(strip):] if strip and n.startswith(strip) else n}.{k}" for n, _ in self._bn_buffers()
+                     for k in ("running_mean", "running_var")]
             if [t[0] for t in btable] != bmine:
                 raise _lib.MMSkinError(f"{type(self).__name__} buffer layout disagrees with the C plan")
             # the reference loop produces three shapes per epoch (full batch, ragged last train batch, ragged last
@@ -300,9 +325,36 @@ class _FlatBackbone(nn.Module):
                 last = m
         return last if last is not None and len(last._forward_hooks) > 0 else None
 
+    def _hooked_features_tail(self):
+        """DenseNet: `model.image_encoder.features[-1]` (norm5), the Grad-CAM++ target of the reference's script
+        (interpretability/gradcam_plusplus.py:298), when it carries forward hooks."""
+        feats = getattr(self, "features", None)
+        if self.arch != "densenet169" or not isinstance(feats, nn.Sequential) or len(feats) == 0:
+            return None
+        return feats[-1] if len(feats[-1]._forward_hooks) > 0 else None
+
+    def _forward_with_features_hooks(self, image, target):
+        """Eval forward of DenseNet up to norm5 on the feature-map plan (same parameter arena), the hooks, then torchvision's
+        tail relu -> adaptive_avg_pool2d(1) -> flatten in torch ops, so autograd.grad(score, activations, create_graph=True)
+        and anything differentiated after it work as in the reference."""
+        if self.training:
+            raise _lib.MMSkinError("forward hooks on features[-1] (Grad-CAM) are supported in eval mode")
+        self._arch_override = "densenet169-features"
+        try:
+            fmap = _BackboneFn.apply(image.detach(), self, False, *[p.detach() for p in self.parameters()])
+        finally:
+            self._arch_override = None
+        acts = fmap.detach().requires_grad_(True)
+        for hook in list(target._forward_hooks.values()):
+            out = hook(target, (None,), acts)
+            if out is not None:
+                acts = out
+        return torch.relu(acts).mean(dim=(2, 3))
+
     def _forward_with_cam_hooks(self, image, conv):
         if self.training or self.arch not in RESNET_DEPTHS:
-            raise _lib.MMSkinError("forward hooks on the last conv (Grad-CAM) are supported for ResNet encoders in eval mode")
+            raise _lib.MMSkinError("forward hooks on the last conv (Grad-CAM) are supported for ResNet encoders in eval mode "
+                                   "(DenseNet: hook image_encoder.features[-1])")
         image = image.detach()
         n, h, w = (image.shape[0], image.shape[1], image.shape[2]) if image.dtype == torch.uint8 else \
             (image.shape[0], image.shape[2], image.shape[3])
@@ -325,6 +377,12 @@ class _FlatBackbone(nn.Module):
     def forward(self, image):
         if not self._packed():
             self._repack()
+        if self.resize_to is not None and image.dtype == torch.uint8:
+            from .preprocess import resize_u8
+            image = resize_u8(image, self.resize_to)
+        tail = self._hooked_features_tail()
+        if tail is not None:
+            return self._forward_with_features_hooks(image, tail)
         conv = self._hooked_last_conv()
         if conv is not None:
             return self._forward_with_cam_hooks(image, conv)
@@ -397,8 +455,9 @@ class _Transition(nn.Module):
         self.pool = nn.AvgPool2d(2, stride=2)
 
 
-class _Features(nn.Module):
-    pass
+class _Features(nn.Sequential):
+    """torchvision's `densenet.features` is an nn.Sequential(OrderedDict): consumers index it (`features[-1]`,
+    gradcam_plusplus.py:298).  The children are holders of parameters; the plan executor runs the arithmetic."""
 
 
 def _build_densenet169_features(f):

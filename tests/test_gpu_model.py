@@ -86,6 +86,63 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
+def _rb(t):
+    return t.bfloat16().float()
+
+
+def bf16_storage_emulation(model):
+    """The CPU oracle with bf16 STORAGE: what any bf16 execution of the network computes, up to summation order.  Conv
+    weights, every conv output, every BatchNorm(+ReLU) output, the max-pool output and every residual-block output are
+    rounded to bf16 (fp32 arithmetic in between); the casts round the gradients flowing back through the same points."""
+    enc = model.image_encoder
+    for m in enc.modules():
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = _rb(m.weight.data)
+            m.register_forward_hook(lambda mod, i, o: _rb(o))
+        elif isinstance(m, (nn.MaxPool2d,)) or type(m).__name__ == "_Residual":
+            m.register_forward_hook(lambda mod, i, o: _rb(o))
+        elif isinstance(m, nn.BatchNorm2d):
+            m.register_forward_hook(lambda mod, i, o: _rb(o))
+    return model
+
+
+def damp_residual_branches(model, gamma):
+    """Set the weight of the LAST BatchNorm of every residual block (bn3 / bn2) to `gamma`: the parameter point of a
+    trained ResNet, whose residual branches are small against the skip path (torchvision's zero_init_residual starts them
+    at 0).  At the default init (1.0) sixteen full-strength random branches make the train-mode network chaotic."""
+    enc = model.image_encoder
+    last = "bn3" if hasattr(enc.layer1[0], "bn3") else "bn2"
+    with torch.no_grad():
+        for n, m in enc.named_modules():
+            if n.endswith("." + last):
+                m.weight.fill_(gamma)
+    return model
+
+
+STAGES = ("conv1|bn1", "layer1", "layer2", "layer3", "layer4")
+
+
+def stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip):
+    """Distances of one train step (logits, loss, running statistics, gradients) from the fp32 CPU oracle's.  Backbone
+    gradients are summarised per ResNet stage: cosine and relative L2 of the stage's concatenated gradient vector."""
+    rec = {"err_train_logits": float((out_c - out_h).abs().max()), "loss_cpu": loss_c, "loss_hip": loss_h}
+    enc_c, enc_h = cpu.image_encoder, hip.image_encoder
+    bns = [(n, m) for n, m in enc_c.named_modules() if isinstance(m, nn.BatchNorm2d)]
+    mods_h = dict(enc_h.named_modules())
+    rec["running_mean_rel_max"] = max(rel_err(mods_h[n].running_mean, m.running_mean) for n, m in bns)
+    rec["running_var_rel_max"] = max(rel_err(mods_h[n].running_var, m.running_var) for n, m in bns)
+    head = [k for k in g_c if not k.startswith("image_encoder")]
+    rec["head_grad_l2_max"] = max(_l2(g_h[k], g_c[k]) for k in head)
+    rec["head_grad_cos_min"] = min(_cos(g_h[k], g_c[k]) for k in head if float(g_c[k].abs().max()) > 0)
+    for st in STAGES:
+        names = st.split("|")
+        keys = [k for k in g_c if any(k.startswith("image_encoder." + n) for n in names)]
+        a = torch.cat([g_h[k].flatten().double() for k in keys]); b = torch.cat([g_c[k].flatten().double() for k in keys])
+        rec["cos_" + names[0]] = _cos(a, b)
+        rec["l2_" + names[0]] = _l2(a, b)
+    return rec
+
+
 @pytest.mark.parametrize("arch,dtype", [("resnet-18", "fp32"), ("resnet-50", "fp32"), ("resnet-50", "bf16")])
 def test_resnet_end_to_end_vs_oracle(arch, dtype):
     """Backbone + crossattention head: eval logits and a full train step against the CPU oracle.
@@ -93,10 +150,14 @@ def test_resnet_end_to_end_vs_oracle(arch, dtype):
     A randomly initialised ResNet at batch 8 is a chaotic map (ReLU sign flips): the CPU fp32 oracle's own
     gradients differ from an fp64 run of the same oracle by ~1-2% (relative L2).  The gradient criterion is
     therefore noise-aware: against the fp64 oracle as truth, the HIP fp32 path may be at most 3x as far away
-    as the CPU fp32 oracle is.  For bf16 compute the north_star only bounds the logits (1e-2); gradients are
-    checked where rounding noise has not yet been amplified (head + last residual block) and for finiteness
-    (a pure-PyTorch emulation that rounds every conv/BN output to bf16 shows the same decorrelation of early
-    layers -- DESIGN.md, Numerics)."""
+    as the CPU fp32 oracle is.
+
+    bf16 compute: at torchvision's default init NO bf16 execution of this train-mode network is within 1e-2 of the fp32
+    logits -- rounding only the matrix-multiply operands to bf16 in the CPU oracle (everything else fp32) already moves
+    them by 3e-2 and decorrelates the early layers' gradients (Numerics).  The reference point for bf16 is
+    therefore `bf16_storage_emulation`: the same oracle with bf16 storage, run on the CPU; the HIP path may be at most
+    1.5x as far from the fp32 oracle as that emulation is, metric by metric.  The 1e-2 bar itself is asserted at the
+    BASELINE shape on a well-conditioned parameter point (test_bf16_train_step_parity_at_baseline_shape)."""
     kw = dict(SMALL, cnn_model_name=arch, common_dim=512, text_encoder_dim_output=512,
               attention_mecanism="crossattention")
     cpu, hip = build_pair(dtype, **kw)
@@ -135,8 +196,106 @@ def test_resnet_end_to_end_vs_oracle(arch, dtype):
         assert head_l2 < 5e-3 and bn_stat < 1e-4
     else:
         assert err_eval < 1e-2, err_eval                                              # north_star: 1e-2 bf16
-        assert err_train < 0.1 and abs(loss_c - loss_h) < 2e-2
-        assert last_cos > 0.85 and head_l2 < 0.4 and bn_stat < 2e-2
+        emu = bf16_storage_emulation(det_init_(OracleMultimodalModel(**dict(kw, device="cpu"))))
+        out_e, loss_e, g_e = _step(emu, _rb(img), meta, lab, "cpu")
+        r_hip = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+        r_emu = stage_report(out_c, loss_c, g_c, out_e, loss_e, g_e, cpu, emu)
+        report(test="e2e_bf16_vs_emulation", arch=arch, hip=r_hip, emu=r_emu)
+        assert_not_worse_than_emulation(r_hip, r_emu, slack=1.5)
+
+
+def assert_not_worse_than_emulation(r_hip, r_emu, slack):
+    """Every distance of the HIP bf16 step from the fp32 oracle is at most `slack` x the distance of the CPU bf16-storage
+    emulation (plus a small absolute floor); every per-stage gradient cosine at least the emulation's minus 0.05."""
+    for k in ("err_train_logits", "running_mean_rel_max", "running_var_rel_max", "head_grad_l2_max"):
+        assert r_hip[k] <= slack * r_emu[k] + 1e-4, (k, r_hip[k], r_emu[k])
+    assert abs(r_hip["loss_hip"] - r_hip["loss_cpu"]) <= slack * abs(r_emu["loss_hip"] - r_emu["loss_cpu"]) + 2e-3
+    for k in r_emu:
+        if k.startswith("cos_"):
+            assert r_hip[k] >= r_emu[k] - 0.05, (k, r_hip[k], r_emu[k])
+        if k.startswith("l2_"):
+            assert r_hip[k] <= slack * r_emu[k] + 1e-3, (k, r_hip[k], r_emu[k])
+
+
+def _baseline_batch(B, hw=224):
+    g = torch.Generator().manual_seed(0)
+    return (torch.randn(B, 3, hw, hw, generator=g), torch.randn(B, 20, generator=g), torch.randint(0, 6, (B,), generator=g))
+
+
+RESNET50_KW = dict(SMALL, cnn_model_name="resnet-50", common_dim=512, text_encoder_dim_output=512, attention_mecanism="crossattention")
+
+
+def test_bf16_train_step_parity_at_baseline_shape():
+    """THE benchmarked path (BASELINE configs[1]): ONE train step (dropout off, BatchNorm batch statistics; the step of
+    train_pad_20.py:102-113) of ResNet-50 + crossattention at B = 256 @ 224^2 with bf16 backbone compute, HIP vs the fp32
+    CPU oracle.  Two parameter points:
+
+    (a) conditioned: the last BatchNorm of every residual block has gamma 0.25 -- residual branches small against the skip
+        path, as in a trained network.  Here the north_star bound means something and is asserted as stated: train-mode
+        logits within 1e-2; plus loss, every BatchNorm's running statistics, head gradients and the per-stage cosine /
+        relative L2 of the backbone gradients (thresholds = 3-5x the values measured on MI355X, gpurun_out/parity_report.jsonl).
+    (b) torchvision's default init (gamma 1): sixteen full-strength random branches make the train-mode network chaotic --
+        no bf16 execution is within 1e-2 (see test_resnet_end_to_end_vs_oracle); the HIP step must be no further from
+        the fp32 oracle than the CPU bf16-storage emulation of the same step (x1.25)."""
+    img, meta, lab = _baseline_batch(256)
+    # ---- (a)
+    cpu, hip = build_pair("bf16", **RESNET50_KW)
+    damp_residual_branches(cpu, 0.25); damp_residual_branches(hip, 0.25)
+    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
+    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+    r = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    report(test="bf16_b256_conditioned", **r)
+    assert set(g_c) == set(g_h) and all(torch.isfinite(v).all() for v in g_h.values())
+    assert r["err_train_logits"] < 1e-2, r                                           # north_star: 1e-2 bf16 (measured 1.4e-3)
+    assert abs(loss_c - loss_h) < 5e-4, r                                            # measured 4e-5
+    assert r["running_mean_rel_max"] < 2e-2 and r["running_var_rel_max"] < 1e-3, r   # measured 3.9e-3 / 6e-5
+    assert r["head_grad_l2_max"] < 0.1 and r["head_grad_cos_min"] > 0.995, r         # measured 2.9e-2 / 0.9996
+    floors = {"cos_conv1": 0.80, "cos_layer1": 0.80, "cos_layer2": 0.82, "cos_layer3": 0.85, "cos_layer4": 0.92}
+    for k, v in floors.items():                                                     # measured 0.876 / 0.884 / 0.892 / 0.914 / 0.964
+        assert r[k] > v, (k, r[k])                                                   # (the CPU bf16 emulation: the same to 3e-3)
+    assert r["l2_layer4"] < 0.4 and r["l2_conv1"] < 0.65, r                          # measured 0.27 / 0.50
+    del cpu, hip, g_c, g_h
+    # ---- (b)
+    cpu, hip = build_pair("bf16", **RESNET50_KW)
+    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
+    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+    r_hip = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    del hip, g_h
+    emu = bf16_storage_emulation(det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu"))))
+    out_e, loss_e, g_e = _step(emu, _rb(img), meta, lab, "cpu")
+    r_emu = stage_report(out_c, loss_c, g_c, out_e, loss_e, g_e, cpu, emu)
+    report(test="bf16_b256_default_init", hip=r_hip, emu=r_emu)
+    assert_not_worse_than_emulation(r_hip, r_emu, slack=1.25)
+
+
+def test_fp32_train_step_parity_at_production_size():
+    """fp32 compute at B = 64 @ 224^2: the code paths that only engage at production size (single-buffer conv variants for
+    launches of > 640 / 800 workgroups, the two-stage slab reduction for > 32 splits, the wgrad split policy, the parity
+    zero fill with large 3-D grids) with a QUANTITATIVE backward check: loss, logits and the encoder gradients
+    -- per stage, plus the stem conv, a layer1 conv3, the layer2 downsample conv and a layer4 BatchNorm -- under the
+    noise-aware rule of test_resnet_end_to_end_vs_oracle (truth = the oracle in fp64; HIP fp32 at most 3x as far as CPU fp32)."""
+    img, meta, lab = _baseline_batch(64)
+    cpu, hip = build_pair("fp32", **RESNET50_KW)
+    truth = det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu"))).double()
+    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
+    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+    truth.train(); disable_dropout(truth)
+    out_t = truth(img.double(), meta.double())
+    nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS, dtype=torch.float64))(out_t, lab).backward()
+    g_t = {k: p.grad for k, p in truth.named_parameters() if p.grad is not None}
+    r = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    picks = ["image_encoder.conv1.weight", "image_encoder.layer1.1.conv3.weight", "image_encoder.layer2.0.downsample.0.weight",
+             "image_encoder.layer4.2.bn3.weight", "image_encoder.layer4.2.bn3.bias"]
+    dist = {k: (_l2(g_h[k], g_t[k]), _l2(g_c[k], g_t[k])) for k in picks}
+    keys = [k for k in g_t if k.startswith("image_encoder")]
+    hip_l2 = sorted(_l2(g_h[k], g_t[k]) for k in keys); cpu_l2 = sorted(_l2(g_c[k], g_t[k]) for k in keys)
+    report(test="fp32_b64_224", picks=dist, hip_l2_median=hip_l2[len(keys) // 2], cpu_l2_median=cpu_l2[len(keys) // 2],
+           hip_l2_max=hip_l2[-1], cpu_l2_max=cpu_l2[-1], **r)
+    assert r["err_train_logits"] < 1e-3 and abs(loss_c - loss_h) < 1e-4, r            # north_star: 1e-3 fp32
+    assert r["running_mean_rel_max"] < 1e-4 and r["running_var_rel_max"] < 1e-4 and r["head_grad_l2_max"] < 5e-3, r
+    for k, (dh, dc) in dist.items():
+        assert dh <= 3 * dc + 1e-4, (k, dh, dc)
+    assert hip_l2[len(keys) // 2] <= 3 * cpu_l2[len(keys) // 2] + 1e-4 and hip_l2[-1] <= 3 * cpu_l2[-1] + 1e-4
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp32"])
@@ -321,6 +480,55 @@ def test_gradcam_consumer_on_last_conv():
     # without hooks the folded inference path is used again and gives the same logits
     with torch.no_grad():
         assert torch.allclose(hip(img.to(DEV), meta.to(DEV)).cpu(), o_c, rtol=1e-3, atol=1e-4)
+
+
+def test_gradcam_on_densenet_features_tail_and_second_order():
+    """SURVEY 8(f)-4 remainder: the reference's Grad-CAM++ script targets `model.image_encoder.features[-1]` on DenseNet
+    (interpretability/gradcam_plusplus.py:298) and calls autograd.grad(score, activations, retain_graph=True,
+    create_graph=True) (:206).  On the HIP model: same indexing, same activations / gradients / CAM as the oracle; the
+    DenseNet tail runs in torch ops, so a SECOND differentiation works too (checked against the oracle), while the ResNet
+    tail raises a clear MMSkinError for it (first-order gradients are exact there)."""
+    from mmskin._lib import MMSkinError
+
+    def run(model, image, meta, target_layer):
+        store = {}
+        h = target_layer.register_forward_hook(lambda mod, i, o: store.__setitem__("a", o))
+        image.requires_grad_(True)
+        out = model(image, meta)
+        score = out[:, 1].sum()
+        acts = store["a"]
+        grads = torch.autograd.grad(score, acts, retain_graph=True, create_graph=True)[0]
+        alpha = grads ** 2 / (2 * grads ** 2 + (acts * grads ** 3).sum(dim=(2, 3), keepdim=True) + 1e-7)
+        cam = torch.relu(((alpha * torch.relu(grads)).sum(dim=(2, 3), keepdim=True) * acts).sum(dim=1))
+        h.remove()
+        return out, acts, grads, cam
+
+    kw = dict(SMALL, cnn_model_name="densenet169", attention_mecanism="concatenation")
+    cpu, hip = build_pair("fp32", **kw)
+    cpu.eval(); hip.eval()
+    assert type(hip.image_encoder.features[-1]).__name__ == "BatchNorm2d"
+    img, meta, _ = det_inputs(2, 64, 20, 6)
+    o_c, a_c, g_c, cam_c = run(cpu, img.clone(), meta, cpu.image_encoder.features[-1])
+    o_h, a_h, g_h, cam_h = run(hip, img.clone().to(DEV), meta.to(DEV), hip.image_encoder.features[-1])
+    assert a_h.shape == a_c.shape == (2, 1664, 2, 2)
+    assert torch.allclose(o_h.detach().cpu(), o_c.detach(), rtol=1e-3, atol=1e-4)
+    assert rel_err(a_h, a_c) < 1e-4 and rel_err(g_h, g_c) < 1e-3 and rel_err(cam_h, cam_c) < 1e-3
+    # second differentiation through the first-order gradient (relu'' = 0, the head is piecewise smooth: LayerNorm terms survive)
+    s_c = torch.autograd.grad((g_c * a_c.detach()).sum(), a_c, allow_unused=True)[0]
+    s_h = torch.autograd.grad((g_h * a_h.detach()).sum(), a_h, allow_unused=True)[0]
+    assert (s_c is None) == (s_h is None)
+    if s_c is not None:
+        assert rel_err(s_h, s_c) < 5e-3
+    with torch.no_grad():                                     # without hooks: the folded inference plan, same logits
+        assert torch.allclose(hip(img.to(DEV), meta.to(DEV)).cpu(), o_c.detach(), rtol=1e-3, atol=1e-4)
+    # ResNet: first order works (test_gradcam_consumer_on_last_conv); a second differentiation says why it cannot
+    kw = dict(SMALL, cnn_model_name="resnet-18", attention_mecanism="concatenation")
+    _, hip = build_pair("fp32", **kw)
+    hip.eval()
+    last = [m for m in hip.image_encoder.modules() if isinstance(m, nn.Conv2d)][-1]
+    _, a_r, g_r, _ = run(hip, img.clone().to(DEV), meta.to(DEV), last)
+    with pytest.raises(MMSkinError, match="second-order"):
+        torch.autograd.grad((g_r * a_r.detach()).sum(), a_r)
 
 
 def test_eval_forward_reuses_staged_weights_only_while_unchanged():

@@ -93,3 +93,41 @@ def test_alternate_models_match_reference_classes(which):
     for k, g in gold["grads"].items():
         if k.startswith(backbone):
             assert abs(summarize(rec["grads"][k])["abs"] - g["abs"]) <= 0.05 * g["abs"] + 1e-7, k
+
+
+def test_resize_restatement_properties():
+    """oracle/preprocess.py (numpy restatement of cv2's 8-bit INTER_LINEAR; cv2 absent -> parity unpinned): identity at
+    equal size, exact 2x2 area average at an exact 2x reduction (cv2 switches to INTER_AREA there, which is
+    (a+b+c+d+2)>>2), within one grey level of float bilinear everywhere, constant images stay constant."""
+    import numpy as np
+    from oracle.preprocess import resize_bilinear_float, resize_linear_u8
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (2, 60, 84, 3), dtype=np.uint8)
+    assert np.array_equal(resize_linear_u8(img, 60, 84), img)
+    area = (img[:, 0::2, 0::2].astype(int) + img[:, 1::2, 0::2] + img[:, 0::2, 1::2] + img[:, 1::2, 1::2] + 2) >> 2
+    assert np.array_equal(resize_linear_u8(img, 30, 42), area.astype(np.uint8))
+    for h, w in ((224, 224), (17, 131), (96, 96)):
+        assert np.abs(resize_linear_u8(img, h, w).astype(float) - resize_bilinear_float(img, h, w)).max() < 1.0
+    assert np.array_equal(resize_linear_u8(np.full((1, 9, 13, 3), 201, np.uint8), 224, 224), np.full((1, 224, 224, 3), 201, np.uint8))
+
+
+def test_metadata_encoder_host_side_matches_sklearn():
+    """mmskin.preprocess.MetadataEncoder.fit / codes (host logic, no GPU): categories, mean, scale and the category
+    indices agree with sklearn's OneHotEncoder / StandardScaler, the reference's own encoders (skinLesionDatasets.py:155-180)."""
+    import numpy as np
+    from sklearn.preprocessing import OneHotEncoder, StandardScaler
+    from mmskin.preprocess import MetadataEncoder
+    rng = np.random.default_rng(3)
+    cats = np.stack([rng.choice(["b", "a", "EMPTY"], 64), rng.choice(["x", "yy", "z", "w"], 64)], axis=1)
+    num = rng.normal(size=(64, 3)); num[5, 1] = np.nan
+    enc = MetadataEncoder().fit(cats, num)
+    ohe = OneHotEncoder(sparse_output=False, handle_unknown="ignore").fit(cats)
+    sc = StandardScaler().fit(np.where(np.isnan(num), -1.0, num))
+    assert all(list(a) == list(b) for a, b in zip(enc.categories_, ohe.categories_))
+    assert np.allclose(enc.mean_, sc.mean_) and np.allclose(enc.scale_, sc.scale_)
+    codes = enc.codes(cats).numpy()
+    onehot = np.zeros((64, enc.onehot_width)); off = 0
+    for j, c in enumerate(enc.categories_):
+        onehot[np.arange(64), off + codes[:, j]] = 1.0; off += len(c)
+    assert np.array_equal(onehot, ohe.transform(cats))
+    assert (enc.codes(np.array([["q", "x"]], dtype=object)).numpy() == [[-1, list(enc.categories_[1]).index("x")]]).all()
