@@ -200,6 +200,11 @@ int mmskin_scale_add_forward(const float* x, const float* b, const float* gamma,
 int mmskin_scale_mul(const float* dy, const float* v, float* out, int64_t n, int C, int per_channel, void* stream);
 int mmskin_token_mean_forward(const float* x, float* out, int B, int L, int E, int start, void* stream);
 int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E, int start, void* stream);
+/* Operand type of the large Linear GEMMs (rows >= 2048, 64-multiple widths: the transformer backbones' and BERT's
+ * projections): MMSKIN_F32 = exact-f32 MFMA (default, parity mode), MMSKIN_BF16 = bf16 operands with fp32 accumulation
+ * (BASELINE configs[3] is quoted in bf16).  Process-wide; the environment variable MMSKIN_LINEAR_DTYPE sets the initial value. */
+int mmskin_set_linear_dtype(int dtype);
+int mmskin_get_linear_dtype(void);
 /* y = a + b, b broadcast over the leading dimension when nb < n (residual sums, position embeddings) */
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream);
 int mmskin_gelu_forward(const float* x, float* y, int64_t n, void* stream);
@@ -227,6 +232,14 @@ int mmskin_embedding_backward(const float* dout, const int64_t* ids, float* dtab
  * col_offset int32 [n_cat + 1] = first one-hot slot of every column (col_offset[n_cat] = onehot_width); numeric fp32
  * [batch][n_num] (NaN = missing -> nan_fill, the reference's fillna(-1)); out fp32 [batch][onehot_width + n_num] =
  * one-hot blocks | (numeric - mean) / scale -- the tensor the reference hands to text_fc. */
+/* Patch extraction for the patch-embedding GEMMs of the timm backbones (PatchEmbed 16x16/16 of ViT / BEiT, DaViT's 7x7/4
+ * stem and 2x2/2 downsample convolutions; loadImageModelClassifier.py:117-121): cols [N*OH*OW][C*k*k], columns ordered
+ * (c, ky, kx) like conv.weight.flatten(1), zeros for padding taps; x is fp32 NCHW (channels_last = 0) or NHWC (= 1).
+ * backward: dx (same layout as x, every element written) = the transpose (sum over the windows containing a pixel). */
+int mmskin_im2col_forward(const float* x, int N, int C, int H, int W, int k, int stride, int pad, int channels_last, float* cols,
+                          void* stream);
+int mmskin_im2col_backward(const float* dcols, int N, int C, int H, int W, int k, int stride, int pad, int channels_last, float* dx,
+                           void* stream);
 int mmskin_resize_u8(const uint8_t* src_nhwc, int N, int src_h, int src_w, uint8_t* dst_nhwc, int dst_h, int dst_w,
                      void* stream);
 int mmskin_metadata_encode(const int32_t* codes, int n_cat, const int32_t* col_offset, int onehot_width, const float* numeric,

@@ -182,9 +182,11 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, float* __rest
 static inline bool linear_big(int M, int K, int N) { return M >= 2048 && K % 64 == 0 && N % 64 == 0; }
 // MMSKIN_LINEAR_DTYPE=bf16: those GEMMs take bf16 operands (fp32 accumulate, fp32 tensors at the boundary): the inputs are
 // converted into library scratch, the bf16 MFMA kernels run, the result is converted back.  Default fp32 (parity mode).
+// The mode is a process-wide setting: MMSKIN_LINEAR_DTYPE at first use, or mmskin_set_linear_dtype() at any time.
+static int g_linear_dtype = -1;   // -1: not read yet; MMSKIN_F32 / MMSKIN_BF16
 static inline bool linear_bf16() {
-  static const bool v = [] { const char* e = getenv("MMSKIN_LINEAR_DTYPE"); return e && !strcmp(e, "bf16"); }();
-  return v;
+  if (g_linear_dtype < 0) { const char* e = getenv("MMSKIN_LINEAR_DTYPE"); g_linear_dtype = (e && !strcmp(e, "bf16")) ? 1 : 0; }
+  return g_linear_dtype == 1;
 }
 __global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1036,6 +1038,12 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
   ARG_CHECK(dout && dx && B > 0 && L > start && E > 0, "token_mean_backward: bad argument");
   EW_LAUNCH(token_mean_bwd_kernel, (int64_t)B * L * E, dout, dx, B, L, E, start);
 }
+int mmskin_set_linear_dtype(int dtype) {
+  ARG_CHECK(dtype == 0 || dtype == 1, "set_linear_dtype: dtype %d (MMSKIN_F32 = 0, MMSKIN_BF16 = 1)", dtype);
+  g_linear_dtype = dtype;
+  return MMSKIN_OK;
+}
+int mmskin_get_linear_dtype(void) { return linear_bf16() ? 1 : 0; }
 int mmskin_add(const float* a, const float* b, float* y, int64_t n, int64_t nb, void* stream) {
   ARG_CHECK(a && b && y && n > 0 && nb > 0 && n % nb == 0, "add: bad argument");
   EW_LAUNCH(add_kernel, n, a, b, y, n, nb);

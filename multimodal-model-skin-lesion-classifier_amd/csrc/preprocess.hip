@@ -73,9 +73,90 @@ __global__ __launch_bounds__(256) void metadata_encode_kernel(const int32_t* __r
   out[i] = v;
 }
 
+// ---- patch extraction (im2col) for the patch-embedding GEMMs of the transformer backbones (timm PatchEmbed / DaViT stem and
+// downsample convolutions, reached through loadImageModelClassifier.py:117-121): rows = (n, oy, ox), columns = (c, ky, kx) --
+// the order of conv.weight.flatten(1) -- so the convolution is ONE Linear over the rows.  The input is addressed through
+// element strides, so NCHW images and NHWC token maps both work without a layout pass.  Out-of-image taps read zeros
+// (padding); rows / columns of the input beyond the last full stride window are simply never read (timm crops / pads the same way).
+struct PatchGeom { int N, C, H, W, k, stride, pad, OH, OW; int64_t sn, sc, sh, sw; };
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, PatchGeom g, float* __restrict__ cols) {
+  const int K = g.C * g.k * g.k;
+  const int64_t total = (int64_t)g.N * g.OH * g.OW * K;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % K);
+    const int64_t row = i / K;
+    const int kx = col % g.k, ky = (col / g.k) % g.k, c = col / (g.k * g.k);
+    const int ox = (int)(row % g.OW), oy = (int)((row / g.OW) % g.OH), n = (int)(row / ((int64_t)g.OW * g.OH));
+    const int iy = oy * g.stride - g.pad + ky, ix = ox * g.stride - g.pad + kx;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) v = x[n * g.sn + c * g.sc + iy * g.sh + ix * g.sw];
+    cols[i] = v;
+  }
+}
+
+// dx[n][c][iy][ix] = sum over the windows that contain the pixel: a gather, so no atomics and a deterministic sum
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcols, PatchGeom g, float* __restrict__ dx) {
+  const int K = g.C * g.k * g.k;
+  const int64_t total = (int64_t)g.N * g.C * g.H * g.W;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i enumerates the input in (n, iy, ix, c) order when the channel stride is 1 (NHWC), else (n, c, iy, ix)
+    int n, c, iy, ix;
+    if (g.sc == 1) { c = (int)(i % g.C); ix = (int)((i / g.C) % g.W); iy = (int)((i / ((int64_t)g.C * g.W)) % g.H); n = (int)(i / ((int64_t)g.C * g.W * g.H)); }
+    else { ix = (int)(i % g.W); iy = (int)((i / g.W) % g.H); c = (int)((i / ((int64_t)g.W * g.H)) % g.C); n = (int)(i / ((int64_t)g.W * g.H * g.C)); }
+    float s = 0.f;
+    for (int ky = (iy + g.pad) % g.stride; ky < g.k; ky += g.stride) {
+      const int oy = (iy + g.pad - ky) / g.stride;
+      if (iy + g.pad - ky < 0 || oy >= g.OH) continue;
+      for (int kx = (ix + g.pad) % g.stride; kx < g.k; kx += g.stride) {
+        const int ox = (ix + g.pad - kx) / g.stride;
+        if (ix + g.pad - kx < 0 || ox >= g.OW) continue;
+        s += dcols[(((int64_t)n * g.OH + oy) * g.OW + ox) * K + (c * g.k + ky) * g.k + kx];
+      }
+    }
+    dx[n * g.sn + c * g.sc + iy * g.sh + ix * g.sw] = s;
+  }
+}
+
+static int patch_geom(PatchGeom& g, int N, int C, int H, int W, int k, int stride, int pad, int channels_last) {
+  ARG_CHECK(N > 0 && C > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0 && H + 2 * pad >= k && W + 2 * pad >= k,
+            "im2col: bad shape N=%d C=%d %dx%d k=%d stride=%d pad=%d", N, C, H, W, k, stride, pad);
+  g.N = N; g.C = C; g.H = H; g.W = W; g.k = k; g.stride = stride; g.pad = pad;
+  g.OH = (H + 2 * pad - k) / stride + 1; g.OW = (W + 2 * pad - k) / stride + 1;
+  if (channels_last) { g.sc = 1; g.sw = C; g.sh = (int64_t)W * C; g.sn = (int64_t)H * W * C; }
+  else { g.sw = 1; g.sh = W; g.sc = (int64_t)H * W; g.sn = (int64_t)C * H * W; }
+  return MMSKIN_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mmskin_im2col_forward(const float* x, int N, int C, int H, int W, int k, int stride, int pad, int channels_last, float* cols,
+                          void* stream) {
+  ARG_CHECK(x && cols, "im2col_forward: null argument");
+  PatchGeom g;
+  int rc = patch_geom(g, N, C, H, W, k, stride, pad, channels_last);
+  if (rc) return rc;
+  const int64_t total = (int64_t)N * g.OH * g.OW * C * k * k;
+  int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)(blocks > (1 << 20) ? (1 << 20) : blocks)), dim3(256), 0, (hipStream_t)stream, x, g, cols);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+int mmskin_im2col_backward(const float* dcols, int N, int C, int H, int W, int k, int stride, int pad, int channels_last, float* dx,
+                           void* stream) {
+  ARG_CHECK(dcols && dx, "im2col_backward: null argument");
+  PatchGeom g;
+  int rc = patch_geom(g, N, C, H, W, k, stride, pad, channels_last);
+  if (rc) return rc;
+  const int64_t total = (int64_t)N * C * H * W;
+  int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)(blocks > (1 << 20) ? (1 << 20) : blocks)), dim3(256), 0, (hipStream_t)stream, dcols, g, dx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
 
 int mmskin_resize_u8(const uint8_t* src_nhwc, int N, int src_h, int src_w, uint8_t* dst_nhwc, int dst_h, int dst_w,
                      void* stream) {

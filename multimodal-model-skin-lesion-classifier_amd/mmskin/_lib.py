@@ -100,6 +100,10 @@ _SIGNATURES = {
     "mmskin_embedding_backward": (_i, [_P] * 3 + [_i] * 4 + [_P]),
     "mmskin_direct_conv2d_forward": (_i, [_P] * 4 + [_i] * 10 + [_P]),
     "mmskin_direct_conv2d_backward": (_i, [_P] * 5 + [_i] * 9 + [_P]),
+    "mmskin_set_linear_dtype": (_i, [_i]),
+    "mmskin_get_linear_dtype": (_i, []),
+    "mmskin_im2col_forward": (_i, [_P] + [_i] * 8 + [_P, _P]),
+    "mmskin_im2col_backward": (_i, [_P] + [_i] * 8 + [_P, _P]),
     "mmskin_resize_u8": (_i, [_P, _i, _i, _i, _P, _i, _i, _P]),
     "mmskin_metadata_encode": (_i, [_P, _i, _P, _i, _P, _i, _P, _P, _f, _P, _i, _P]),
     "mmskin_pool_gap_forward": (_i, [_P] * 3 + [_i] * 5 + [_P]),

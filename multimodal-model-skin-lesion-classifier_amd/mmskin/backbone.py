@@ -11,6 +11,7 @@ import ctypes
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.nn as nn
 
 from . import _lib, ops
@@ -147,6 +148,7 @@ class _BackboneFn(torch.autograd.Function):
         return feats
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dfeat):
         module, plan = ctx.module, ctx.plan
         if not ctx.training_fwd:

@@ -5,6 +5,7 @@ the HIP kernels on torch's current stream through ctypes and keeps what the
 matching backward entry point needs.  No arithmetic happens in PyTorch here.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import call, ptr, stream
@@ -41,6 +42,7 @@ class LinearFn(torch.autograd.Function):
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x2, w, y = ctx.saved_tensors
         M, K = x2.shape
@@ -80,6 +82,7 @@ class LayerNormFn(torch.autograd.Function):
         return y.reshape(x.shape)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x2, g, b, mean, rstd = ctx.saved_tensors
         M, N = x2.shape
@@ -109,6 +112,7 @@ class SigmoidGateFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         z, v = ctx.saved_tensors
         dout = _f32c(dout)
@@ -133,6 +137,7 @@ class GatedMixFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         z, a, q = ctx.saved_tensors
         dout = _f32c(dout)
@@ -158,6 +163,7 @@ class MetaBlockGateFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         V, t1, t2 = ctx.saved_tensors
         dout = _f32c(dout)
@@ -183,6 +189,7 @@ class DropoutFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -216,6 +223,7 @@ class Concat2Fn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         M, Na, Nb = ctx.dims
         dout = _f32c(dout)
@@ -245,6 +253,7 @@ class AttentionFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dO):
         q, k, v, p = ctx.saved_tensors
         B, H, L, Dh = q.shape
@@ -292,6 +301,7 @@ class LongAttentionFn(torch.autograd.Function):
         return o
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dO):
         q, k, v, probs, pd, dmask = ctx.saved_tensors
         B, H, L, Dh = q.shape
@@ -351,6 +361,7 @@ class MDNetFuseFn(torch.autograd.Function):
         return pooled
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dp):
         feat, z, t1, t2 = ctx.saved_tensors
         N, C, H, W = feat.shape
@@ -379,6 +390,7 @@ class AddFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         db = dy if ctx.lead == 1 else dy.reshape(ctx.lead, -1).sum(0).reshape(ctx.bshape)
         return dy, db
@@ -400,6 +412,7 @@ class ScaleAddFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         b, gamma = ctx.saved_tensors
         dy = _f32c(dy)
@@ -430,6 +443,7 @@ class TokenMeanFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         B, L, E, start = ctx.dims
         dout = _f32c(dout)
@@ -439,6 +453,47 @@ class TokenMeanFn(torch.autograd.Function):
 
 
 token_mean = TokenMeanFn.apply
+
+
+def set_linear_dtype(name):
+    """'fp32' (exact-f32 MFMA, default) or 'bf16' (bf16 operands, fp32 accumulate) for the large Linear GEMMs."""
+    call("mmskin_set_linear_dtype", {"fp32": _lib.F32, "float32": _lib.F32, "bf16": _lib.BF16, "bfloat16": _lib.BF16}[name.lower()])
+
+
+def get_linear_dtype():
+    return "bf16" if _lib.load().mmskin_get_linear_dtype() == 1 else "fp32"
+
+
+class PatchColsFn(torch.autograd.Function):
+    """im2col for the patch-embedding GEMMs: x [N, C, H, W] (channels_last=False) or [N, H, W, C] (True), fp32 ->
+    cols [N*OH*OW, C*k*k] with columns ordered (c, ky, kx) like conv.weight.flatten(1); zero padding."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, channels_last):
+        _need_gpu(x, "patch_cols")
+        x = _f32c(x)
+        if channels_last:
+            N, H, W, C = x.shape
+        else:
+            N, C, H, W = x.shape
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        cols = torch.empty((N * OH * OW, C * k * k), device=x.device, dtype=torch.float32)
+        call("mmskin_im2col_forward", ptr(x), N, C, H, W, k, stride, pad, int(channels_last), ptr(cols), stream())
+        ctx.geom = (N, C, H, W, k, stride, pad, int(channels_last), tuple(x.shape))
+        return cols
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcols):
+        N, C, H, W, k, stride, pad, cl, shape = ctx.geom
+        dcols = _f32c(dcols)
+        dx = torch.empty(shape, device=dcols.device, dtype=torch.float32)
+        call("mmskin_im2col_backward", ptr(dcols), N, C, H, W, k, stride, pad, cl, ptr(dx), stream())
+        return dx, None, None, None, None
+
+
+def patch_cols(x, k, stride, pad=0, channels_last=False):
+    return PatchColsFn.apply(x, k, stride, pad, channels_last)
 
 
 class DwConv3Fn(torch.autograd.Function):
@@ -456,6 +511,7 @@ class DwConv3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         N, H, W, C = x.shape
@@ -483,6 +539,7 @@ class GeluFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -505,6 +562,7 @@ class GeluTanhFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -533,6 +591,7 @@ class EmbeddingFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         B, ncols, card, E = ctx.dims
@@ -563,6 +622,7 @@ class DirectConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
@@ -595,6 +655,7 @@ class PoolGapFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         N, C, H, W, k = ctx.cfg

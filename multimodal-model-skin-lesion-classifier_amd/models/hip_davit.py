@@ -185,13 +185,15 @@ class HipDaVit(nn.Module):
 
     def forward_features(self, image):                                   # -> [B, H/32, W/32, C]
         x = image.float()
-        ph, pw = (4 - x.shape[2] % 4) % 4, (4 - x.shape[3] % 4) % 4
-        if ph or pw:
-            x = torch.nn.functional.pad(x, (0, pw, 0, ph))
-        # 7x7/4 stem conv (pad 3) as a Linear over unfolded 7x7x3 patches (im2col is a data-layout step)
+        # 7x7/4 stem conv (pad 3) = HIP patch extraction (zero padding in the kernel) + ONE Linear over the 147-wide rows.
+        # timm pads the image to a multiple of 4 first; with pad 3 / stride 4 the output grid ceil(H/4) x ceil(W/4) and every
+        # tap value are the same whether those zeros are materialised or come from the kernel's bounds check.
         B, _, Hi, Wi = x.shape
-        H, W = (Hi + 6 - 7) // 4 + 1, (Wi + 6 - 7) // 4 + 1
-        cols = torch.nn.functional.unfold(x, kernel_size=7, padding=3, stride=4).transpose(1, 2).reshape(B * H * W, 147).contiguous()
+        H, W = (Hi + 3) // 4, (Wi + 3) // 4
+        Hi_p, Wi_p = 4 * H, 4 * W
+        if (Hi_p, Wi_p) != (Hi, Wi):       # ragged sizes only: the kernel's geometry is defined by the padded extent
+            xp = x.new_zeros((B, 3, Hi_p, Wi_p)); xp[:, :, :Hi, :Wi] = x; x = xp
+        cols = ops.patch_cols(x, 7, 4, 3)
         x = ops.linear(cols, self.stem.conv.weight.flatten(1), self.stem.conv.bias)
         C = x.shape[1]
         x = _layernorm(self.stem.norm, x).reshape(B, H, W, C)
@@ -203,8 +205,8 @@ class HipDaVit(nn.Module):
                 if H % 2 or W % 2:
                     x = torch.nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2))
                     B, H, W, C = x.shape
-                p = x.reshape(B, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(B * (H // 2) * (W // 2), C * 4).contiguous()
-                x = ops.linear(p, ds.conv.weight.flatten(1), ds.conv.bias).reshape(B, H // 2, W // 2, -1)   # columns ordered (c, kh, kw)
+                p = ops.patch_cols(x, 2, 2, 0, channels_last=True)                                          # columns ordered (c, kh, kw)
+                x = ops.linear(p, ds.conv.weight.flatten(1), ds.conv.bias).reshape(B, H // 2, W // 2, -1)
             for pair in stage.blocks:
                 x = pair[1](pair[0](x))
         return x

@@ -44,8 +44,8 @@ class _PatchEmbed(nn.Module):
         B, C, H, W = x.shape
         P = self.patch
         gh, gw = H // P, W // P
-        patches = x[:, :, :gh * P, :gw * P].reshape(B, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * P * P)
-        y = ops.linear(patches.contiguous(), self.proj.weight.flatten(1), self.proj.bias)
+        patches = ops.patch_cols(x, P, P, 0)          # HIP im2col: rows (b, gy, gx), columns (c, ky, kx); the ragged edge is never read
+        y = ops.linear(patches, self.proj.weight.flatten(1), self.proj.bias)
         return y.reshape(B, gh * gw, -1)
 
 
