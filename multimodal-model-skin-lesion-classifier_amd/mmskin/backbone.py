@@ -11,10 +11,10 @@ import ctypes
 import os
 
 import torch
-from torch.autograd.function import once_differentiable
 import torch.nn as nn
 
 from . import _lib, ops
+from ._autograd import no_second_order
 from ._lib import call, ptr, stream
 
 RESNET_DEPTHS = {"resnet-18": (False, (2, 2, 2, 2)), "resnet-50": (True, (3, 4, 6, 3))}
@@ -105,6 +105,7 @@ class _Plan:
             pass
 
 
+@no_second_order
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, module, training, *params):
@@ -148,7 +149,6 @@ class _BackboneFn(torch.autograd.Function):
         return feats
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dfeat):
         module, plan = ctx.module, ctx.plan
         if not ctx.training_fwd:
@@ -200,11 +200,11 @@ class _CamTailFn(torch.autograd.Function):
         if torch.is_grad_enabled() and dfeat.requires_grad:
             # create_graph=True (cam.py:38-43): the FIRST-order gradient above is what Grad-CAM++ uses (it squares and cubes
             # it elementwise).  Differentiating THROUGH it a second time is not implemented on the HIP path: say so.
-            dx = _NoSecondOrder.apply(dx, dfeat)
+            dx = _CamNoSecondOrder.apply(dx, dfeat)
         return dx, None, None
 
 
-class _NoSecondOrder(torch.autograd.Function):
+class _CamNoSecondOrder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dx, dfeat):
         return dx.view_as(dx)

@@ -5,9 +5,9 @@ the HIP kernels on torch's current stream through ctypes and keeps what the
 matching backward entry point needs.  No arithmetic happens in PyTorch here.
 """
 import torch
-from torch.autograd.function import once_differentiable
 
 from . import _lib
+from ._autograd import no_second_order
 from ._lib import call, ptr, stream
 
 
@@ -24,6 +24,7 @@ def _f32c(t):
     return t.contiguous()
 
 
+@no_second_order
 class LinearFn(torch.autograd.Function):
     """y = x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU])."""
 
@@ -42,7 +43,6 @@ class LinearFn(torch.autograd.Function):
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x2, w, y = ctx.saved_tensors
         M, K = x2.shape
@@ -62,6 +62,7 @@ def linear(x, w, b=None, relu=False):
     return LinearFn.apply(x, w, b, relu)
 
 
+@no_second_order
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dim, optional fused ReLU."""
 
@@ -82,7 +83,6 @@ class LayerNormFn(torch.autograd.Function):
         return y.reshape(x.shape)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x2, g, b, mean, rstd = ctx.saved_tensors
         M, N = x2.shape
@@ -99,6 +99,7 @@ def layernorm(x, g, b, eps=1e-5, relu=False):
     return LayerNormFn.apply(x, g, b, eps, relu)
 
 
+@no_second_order
 class SigmoidGateFn(torch.autograd.Function):
     """sigmoid(z) * v."""
 
@@ -112,7 +113,6 @@ class SigmoidGateFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         z, v = ctx.saved_tensors
         dout = _f32c(dout)
@@ -124,6 +124,7 @@ class SigmoidGateFn(torch.autograd.Function):
 sigmoid_gate = SigmoidGateFn.apply
 
 
+@no_second_order
 class GatedMixFn(torch.autograd.Function):
     """g*a + (1-g)*q with g = sigmoid(z)."""
 
@@ -137,7 +138,6 @@ class GatedMixFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         z, a, q = ctx.saved_tensors
         dout = _f32c(dout)
@@ -150,6 +150,7 @@ class GatedMixFn(torch.autograd.Function):
 gated_mix = GatedMixFn.apply
 
 
+@no_second_order
 class MetaBlockGateFn(torch.autograd.Function):
     """sigmoid(tanh(V*t1) + t2)."""
 
@@ -163,7 +164,6 @@ class MetaBlockGateFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         V, t1, t2 = ctx.saved_tensors
         dout = _f32c(dout)
@@ -176,6 +176,7 @@ class MetaBlockGateFn(torch.autograd.Function):
 metablock_gate = MetaBlockGateFn.apply
 
 
+@no_second_order
 class DropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed, offset):
@@ -189,7 +190,6 @@ class DropoutFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -210,6 +210,7 @@ def dropout(x, p, training):
     return DropoutFn.apply(x, p, seed, _dropout_counter[0])
 
 
+@no_second_order
 class Concat2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -223,7 +224,6 @@ class Concat2Fn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         M, Na, Nb = ctx.dims
         dout = _f32c(dout)
@@ -236,6 +236,7 @@ class Concat2Fn(torch.autograd.Function):
 concat2 = Concat2Fn.apply
 
 
+@no_second_order
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(Dh)) v on [B, H, L, Dh] tensors; optional dropout on the probabilities."""
 
@@ -253,7 +254,6 @@ class AttentionFn(torch.autograd.Function):
         return o
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dO):
         q, k, v, p = ctx.saved_tensors
         B, H, L, Dh = q.shape
@@ -268,6 +268,7 @@ def _bmm(a, b, c, batch, M, N, K, sam, sak, sab, sbn, sbk, sbb, ldc, scb):
     call("mmskin_bmm", ptr(a), ptr(b), ptr(c), batch, M, N, K, sam, sak, sab, sbn, sbk, sbb, ldc, scb, stream())
 
 
+@no_second_order
 class LongAttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(Dh) + mask) v for sequences whose score matrix does not fit one workgroup's LDS
     (BERT: L = 512): strided batched GEMMs + a row-softmax kernel, the probabilities kept for backward.
@@ -301,7 +302,6 @@ class LongAttentionFn(torch.autograd.Function):
         return o
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dO):
         q, k, v, probs, pd, dmask = ctx.saved_tensors
         B, H, L, Dh = q.shape
@@ -347,6 +347,7 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, 
     return AttentionFn.apply(q, k, v, p, seed, offset)
 
 
+@no_second_order
 class MDNetFuseFn(torch.autograd.Function):
     """mean_hw(sigmoid(z) * f + sigmoid(tanh(f * t1) + t2)) for f [N, C, H, W]; z, t1, t2 [N, C] -> [N, C]."""
 
@@ -361,7 +362,6 @@ class MDNetFuseFn(torch.autograd.Function):
         return pooled
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dp):
         feat, z, t1, t2 = ctx.saved_tensors
         N, C, H, W = feat.shape
@@ -376,6 +376,7 @@ class MDNetFuseFn(torch.autograd.Function):
 mdnet_fuse = MDNetFuseFn.apply
 
 
+@no_second_order
 class AddFn(torch.autograd.Function):
     """a + b with b broadcast over a's leading dimensions (residual sums, position embeddings)."""
 
@@ -390,7 +391,6 @@ class AddFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         db = dy if ctx.lead == 1 else dy.reshape(ctx.lead, -1).sum(0).reshape(ctx.bshape)
         return dy, db
@@ -399,6 +399,7 @@ class AddFn(torch.autograd.Function):
 add = AddFn.apply
 
 
+@no_second_order
 class ScaleAddFn(torch.autograd.Function):
     """x + gamma[c] * b   (timm LayerScale residual: x + gamma_1 * attn(norm1(x)))."""
 
@@ -412,7 +413,6 @@ class ScaleAddFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         b, gamma = ctx.saved_tensors
         dy = _f32c(dy)
@@ -429,6 +429,7 @@ class ScaleAddFn(torch.autograd.Function):
 scale_add = ScaleAddFn.apply
 
 
+@no_second_order
 class TokenMeanFn(torch.autograd.Function):
     """mean over tokens [start, L) of x [B, L, E]   (timm global_pool='avg' over the patch tokens)."""
 
@@ -443,7 +444,6 @@ class TokenMeanFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         B, L, E, start = ctx.dims
         dout = _f32c(dout)
@@ -464,6 +464,7 @@ def get_linear_dtype():
     return "bf16" if _lib.load().mmskin_get_linear_dtype() == 1 else "fp32"
 
 
+@no_second_order
 class PatchColsFn(torch.autograd.Function):
     """im2col for the patch-embedding GEMMs: x [N, C, H, W] (channels_last=False) or [N, H, W, C] (True), fp32 ->
     cols [N*OH*OW, C*k*k] with columns ordered (c, ky, kx) like conv.weight.flatten(1); zero padding."""
@@ -483,7 +484,6 @@ class PatchColsFn(torch.autograd.Function):
         return cols
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dcols):
         N, C, H, W, k, stride, pad, cl, shape = ctx.geom
         dcols = _f32c(dcols)
@@ -496,6 +496,7 @@ def patch_cols(x, k, stride, pad=0, channels_last=False):
     return PatchColsFn.apply(x, k, stride, pad, channels_last)
 
 
+@no_second_order
 class DwConv3Fn(torch.autograd.Function):
     """Depthwise 3x3 (stride 1, pad 1) on NHWC fp32: x [N, H, W, C], w [C, 1, 3, 3] -> [N, H, W, C]."""
 
@@ -511,7 +512,6 @@ class DwConv3Fn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         N, H, W, C = x.shape
@@ -528,6 +528,7 @@ class DwConv3Fn(torch.autograd.Function):
 dwconv3 = DwConv3Fn.apply
 
 
+@no_second_order
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -539,7 +540,6 @@ class GeluFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -551,6 +551,7 @@ class GeluFn(torch.autograd.Function):
 gelu = GeluFn.apply
 
 
+@no_second_order
 class GeluTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -562,7 +563,6 @@ class GeluTanhFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         dy = _f32c(dy)
@@ -574,6 +574,7 @@ class GeluTanhFn(torch.autograd.Function):
 gelu_tanh = GeluTanhFn.apply
 
 
+@no_second_order
 class EmbeddingFn(torch.autograd.Function):
     """table [ncols, card, E], ids [B, ncols] -> [B, ncols, E]."""
 
@@ -591,7 +592,6 @@ class EmbeddingFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         B, ncols, card, E = ctx.dims
@@ -604,6 +604,7 @@ class EmbeddingFn(torch.autograd.Function):
 embedding = EmbeddingFn.apply
 
 
+@no_second_order
 class DirectConvFn(torch.autograd.Function):
     """Small direct NCHW conv (+bias, optional ReLU) for the `custom-cnn` stem (no input gradient)."""
 
@@ -622,7 +623,6 @@ class DirectConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         stride, pad, has_bias = ctx.cfg
@@ -639,6 +639,7 @@ class DirectConvFn(torch.autograd.Function):
 direct_conv2d = DirectConvFn.apply
 
 
+@no_second_order
 class PoolGapFn(torch.autograd.Function):
     """MaxPool2d(k) followed by AdaptiveAvgPool2d(1)+Flatten: [N,C,H,W] -> [N,C]."""
 
@@ -655,7 +656,6 @@ class PoolGapFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         N, C, H, W, k = ctx.cfg

@@ -216,3 +216,36 @@ def test_timm_branch_davit_layout():
     import pytest
     with pytest.raises(ValueError):
         loadModels.loadModelImageEncoder("mvitv2_small.fb_in1k", 64, "frozen_weights")
+
+
+def test_second_order_through_a_hip_op_raises_instead_of_folding_constants():
+    """mmskin._autograd.no_second_order (wraps every HIP autograd.Function): first-order gradients under create_graph=True
+    are returned unchanged; differentiating through them again raises MMSkinError -- torch would otherwise treat the opaque
+    backward's result as a constant and return a silently wrong second-order gradient (host logic, no GPU needed)."""
+    import pytest
+    import torch
+    from mmskin._autograd import no_second_order
+    from mmskin._lib import MMSkinError
+
+    @no_second_order
+    class Cube(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return w * x ** 3
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            return (3 * w * x ** 2 * g).detach(), (x ** 3 * g).detach()     # opaque: no graph, like a kernel launch
+
+    x = torch.tensor([1.0, -2.0], requires_grad=True)
+    w = torch.tensor([0.5, 2.0], requires_grad=True)
+    y = Cube.apply(x, w).sum()
+    gx, gw = torch.autograd.grad(y, (x, w), create_graph=True)
+    assert torch.allclose(gx, 3 * w * x ** 2) and torch.allclose(gw, x ** 3)
+    for target in (x, w):                                     # anchored on EVERY differentiable input
+        with pytest.raises(MMSkinError, match="second-order"):
+            torch.autograd.grad(gx.sum(), target, retain_graph=True)
+    Cube.apply(x, w).sum().backward()                         # the ordinary path is untouched
+    assert torch.allclose(x.grad, (3 * w * x ** 2).detach()) and torch.allclose(w.grad, (x ** 3).detach())
