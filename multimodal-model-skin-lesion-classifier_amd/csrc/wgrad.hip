@@ -316,6 +316,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4* __rest
     if (c + j < Cv) dw[((size_t)cout * Cv + c + j) * ntaps + tap] = v[j];
 }
 
+// Many splits (> WG_DIRECT_SPLITS) in ONE launch: 64 float4 columns x 4 row lanes per block; a lane walks every 4th slab with four
+// independent accumulators, the lanes meet in LDS, lane 0 scatters to OIHW.  Replaces the group pre-reduction + final reduction
+// pair (two launches per layer on the weight-gradient stream, ~25 pairs per ResNet-50 step).  Deterministic (fixed order).
+__global__ __launch_bounds__(256) void wgrad_reduce4_lanes_kernel(const float4* __restrict__ slab, float* __restrict__ dw, int nsplit,
+                                                                  int Cout, int C, int ntaps, int Coutv, int Cv) {
+  __shared__ float4 red[4][64];
+  const int Ktot = C * ntaps;
+  const int total4 = Cout * (Ktot / 4);
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cx;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+#define ACC4(a, u) a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+  if (i < total4) {
+    const float4* src = slab + (size_t)ry * total4 + i;
+    int k = ry;
+    for (; k + 12 < nsplit; k += 16, src += (size_t)16 * total4) {
+      const float4 u0 = src[0], u1 = src[(size_t)4 * total4], u2 = src[(size_t)8 * total4], u3 = src[(size_t)12 * total4];
+      ACC4(a0, u0) ACC4(a1, u1) ACC4(a2, u2) ACC4(a3, u3)
+    }
+    for (; k < nsplit; k += 4, src += (size_t)4 * total4) { const float4 u = src[0]; ACC4(a0, u) }
+  }
+  red[ry][cx] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (ry != 0 || i >= total4) return;
+  float4 t = red[0][cx];
+  ACC4(t, red[1][cx]) ACC4(t, red[2][cx]) ACC4(t, red[3][cx])
+#undef ACC4
+  const float v[4] = {t.x, t.y, t.z, t.w};
+  const int e = i * 4;
+  const int cout = e / Ktot, kk = e - cout * Ktot;
+  const int tap = kk / C, c = kk - tap * C;
+  if (cout >= Coutv) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (c + j < Cv) dw[((size_t)cout * Cv + c + j) * ntaps + tap] = v[j];
+}
+
 // ------------------------------------------------------------------------------------------ host
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static void wgrad_plan(int M, int Cout, int Ktot, int MS, int& BO, int& BKK, int& nsplit, int& mps, int ntaps = 1) {
@@ -353,6 +390,14 @@ static int reduce_slabs(float* slab, int nsplit, int Cout, int Ktot, float* dw, 
   const int total4 = (int)(total / 4);
   const float* src = slab;
   int nsrc = nsplit;
+  static const int one_launch = env_int("MMSKIN_WGRAD_REDUCE_ONE", 1);
+  if (one_launch && nsplit > WG_DIRECT_SPLITS && C_for_layout % 4 == 0) {
+    const int coutv = cout_valid > 0 ? cout_valid : Cout, cv = cin_valid > 0 ? cin_valid : C_for_layout;
+    hipLaunchKernelGGL(wgrad_reduce4_lanes_kernel, dim3(ceil_div(total4, 64)), dim3(256), 0, st, reinterpret_cast<const float4*>(slab),
+                       dw, nsplit, Cout, C_for_layout, ntaps_for_layout, coutv, cv);
+    HIP_CHECK_RET(hipGetLastError());
+    return MMSKIN_OK;
+  }
   if (nsplit > WG_DIRECT_SPLITS) {   // many small splits: wide first-stage reduction to G <= WG_GROUPS partial slabs
     float* slab2 = slab + (size_t)nsplit * total;
     // >= 256k threads where the output allows it, <= 32 rows per thread, at least 2 rows per group
