@@ -200,6 +200,18 @@ int mmskin_scale_add_forward(const float* x, const float* b, const float* gamma,
 int mmskin_scale_mul(const float* dy, const float* v, float* out, int64_t n, int C, int per_channel, void* stream);
 int mmskin_token_mean_forward(const float* x, float* out, int B, int L, int E, int start, void* stream);
 int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E, int start, void* stream);
+/* Fused attention, bf16 MFMA with fp32 accumulation / softmax / I/O:  o = dropout(softmax(q k^T * scale + bias + mask)) v  in one
+ * kernel; the [B, H, L, L] scores never reach memory.  Replaces the QK^T GEMM -> softmax -> dropout -> PV GEMM chain of the
+ * transformer encoders (timm ViT / BEiT blocks, transformers' BertSelfAttention / GPT2Attention; loadImageModelClassifier.py
+ * :117-121, :170-181) in bf16-operand mode.  q, k, v, o: fp32, element (b, h, l, d) at ptr + b*sb + h*sh + l*sl + d, the twelve
+ * strides given as strides12 = {q_sb, q_sh, q_sl, k_*, v_*, o_*} (multiples of 4; pointers 16-byte aligned), so the output of a
+ * fused qkv Linear is read in place.  mask_add [B][L] additive key mask or NULL; bias [H][L][L] additive score bias or NULL
+ * (BEiT's relative-position bias); causal != 0: key j > query i masked; drop_p: dropout on the probabilities with the library's
+ * counter-based generator on the element index of the [B, H, L, L] tensor (seed, offset as mmskin_dropout_forward);
+ * lse (optional) [B][H][L] = log-sum-exp of the scaled, biased scores.  Dh in {32, 64, 128}. */
+int mmskin_flash_attention_forward(const float* q, const float* k, const float* v, const float* mask_add, const float* bias,
+                                   float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
+                                   int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 /* Operand type of the large Linear GEMMs (rows >= 2048, 64-multiple widths: the transformer backbones' and BERT's
  * projections): MMSKIN_F32 = exact-f32 MFMA (default, parity mode), MMSKIN_BF16 = bf16 operands with fp32 accumulation
  * (BASELINE configs[3] is quoted in bf16).  Process-wide; the environment variable MMSKIN_LINEAR_DTYPE sets the initial value. */

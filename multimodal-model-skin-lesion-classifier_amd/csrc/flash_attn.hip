@@ -1,0 +1,260 @@
+// Fused softmax attention for gfx950:  O = dropout(softmax(Q K^T * scale + bias + key_mask)) V   in ONE kernel.
+//
+// Replaces, in bf16-operand mode, the chain the transformer encoders of the reference reach through timm / transformers
+// (loadImageModelClassifier.py:117-121 `timm.create_model`, :170-181 `AutoModel.from_pretrained`; consumed at
+// multimodalIntraInterModal.py:167,180-183): QK^T GEMM -> row softmax (+ relative-position bias / key padding mask /
+// causal mask) -> dropout -> PV GEMM, which as separate fp32 launches materialised the [B, H, L, L] scores three times
+// (47 % of a BEiT-large + BERT step, profiles/r02_*).  Here the scores never leave the chip:
+//
+//   * one 256-thread workgroup = 64 query rows of one (batch, head); wave w owns rows 16w..16w+15
+//   * K / V are walked in 64-key tiles: fp32 global -> registers (the next tile's loads are in flight while this tile is
+//     multiplied) -> bf16 -> LDS (row pitch D*2 + 16 B: conflict-free for both the b128 row reads of K and the
+//     transposing reads of V)
+//   * S = Q K^T on v_mfma_f32_16x16x32_bf16 (Q fragments live in registers for the whole kernel, pre-multiplied by
+//     `scale`); online softmax in fp32 registers (running max / sum per query row, 16-lane xor-shuffle reductions);
+//     P -> bf16 -> a wave-private LDS tile (the accumulator layout holds a key per lane, the A operand needs a query per
+//     lane) -> O += P V on the same MFMA, V fragments by ds_read_b64_tr_b16
+//   * dropout uses the library's counter-based generator on the element index of the [B, H, L, L] probability tensor, so
+//     a fused launch drops exactly the elements the unfused path would
+//   * q / k / v / o are addressed through element strides: the [B, L, 3, H, Dh] output of a fused qkv Linear is read in
+//     place and O can be written token-major, without permute copies
+// fp32 tensors at the boundary (the host ops are fp32), fp32 accumulation and softmax; LSE is written for a backward pass.
+#include "../../include/mmskin.h"
+#include "common.h"
+
+namespace {
+
+struct FlashArgs {
+  const float* q; const float* k; const float* v;
+  float* o; float* lse;
+  const float* mask_add;   // [B][L] additive key mask or null
+  const float* bias;       // [H][L][L] additive score bias or null
+  int B, H, L;
+  int64_t q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sh, o_sl;   // element strides (last dim contiguous)
+  float scale, drop_p;
+  int causal;
+  uint64_t seed, offset;
+};
+
+__device__ __forceinline__ uint64_t fa_mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
+  constexpr int BQ = 64, BK = 64;
+  constexpr int PITCH = D * 2 + 16;          // bytes per K / V row in LDS
+  constexpr int PPITCH = BK * 2 + 16;        // bytes per P row
+  constexpr int KS = D / 32;                 // k-steps of the QK^T product
+  constexpr int DN = D / 16;                 // 16-wide output column tiles
+  constexpr int CPT = BK * (D / 4) / 256;    // float4 chunks per thread per tile (K and V each)
+  static_assert(D == 32 || D == 64 || D == 128, "head dim");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * PITCH + 4 * 16 * PPITCH];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + BK * PITCH;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+  unsigned char* Ps = smem + 2 * BK * PITCH + wid * 16 * PPITCH;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = blockIdx.x * BQ;
+  const int L = p.L;
+
+  // ---- Q fragments: lane (row l15 of this wave's 16, d = 32 ks + 8 g .. +7), scaled, bf16
+  uint4 qf[KS];
+  {
+    const int qi = q0 + wid * 16 + l15;
+    const float* qp = p.q + b * p.q_sb + h * p.q_sh + (int64_t)(qi < L ? qi : L - 1) * p.q_sl;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a = *reinterpret_cast<const float4*>(qp + 32 * ks + 8 * g);
+      const float4 c = *reinterpret_cast<const float4*>(qp + 32 * ks + 8 * g + 4);
+      qf[ks] = make_uint4(pack_bf16(a.x * p.scale, a.y * p.scale), pack_bf16(a.z * p.scale, a.w * p.scale),
+                          pack_bf16(c.x * p.scale, c.y * p.scale), pack_bf16(c.z * p.scale, c.w * p.scale));
+    }
+  }
+  // rows this lane owns in the accumulator layout: query 4 g + r of the wave's 16
+  float m_run[4], l_run[4];
+  f32x4_t oacc[DN];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < DN; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const float* kbase = p.k + b * p.k_sb + h * p.k_sh;
+  const float* vbase = p.v + b * p.v_sb + h * p.v_sh;
+  const int nt_all = (L + BK - 1) / BK;
+  // causal: key tiles beyond this workgroup's last query row contribute nothing
+  const int nt = p.causal ? min(nt_all, (min(q0 + BQ, L) + BK - 1) / BK) : nt_all;
+
+  float4 kr[CPT], vr[CPT];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + 256 * i, key = c / (D / 4), dc = c - key * (D / 4);
+      const int kj = t * BK + key;
+      if (kj < L) {
+        kr[i] = *reinterpret_cast<const float4*>(kbase + (int64_t)kj * p.k_sl + dc * 4);
+        vr[i] = *reinterpret_cast<const float4*>(vbase + (int64_t)kj * p.v_sl + dc * 4);
+      } else {
+        kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + 256 * i, key = c / (D / 4), dc = c - key * (D / 4);
+      *reinterpret_cast<uint2*>(Ks + key * PITCH + dc * 8) = make_uint2(pack_bf16(kr[i].x, kr[i].y), pack_bf16(kr[i].z, kr[i].w));
+      *reinterpret_cast<uint2*>(Vs + key * PITCH + dc * 8) = make_uint2(pack_bf16(vr[i].x, vr[i].y), pack_bf16(vr[i].z, vr[i].w));
+    }
+  };
+
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const uint64_t seed_mix = fa_mix64(p.seed);
+  const int q_lane0 = q0 + wid * 16 + 4 * g;      // first of this lane's 4 query rows
+  const int tq = l15 >> 2, tp = l15 & 3;          // transposing-read roles inside a 16-lane group
+
+  if (nt > 0) load_tile(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();                 // every wave is done with the previous tile's K / V (and P)
+    store_tile();
+    __syncthreads();
+    if (t + 1 < nt) load_tile(t + 1);   // in flight under this tile's MFMAs
+
+    // ---- S = (scale Q) K^T : 4 key groups of 16
+    f32x4_t s[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      s[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (16 * n + l15) * PITCH + (32 * ks + 8 * g) * 2);
+        s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[ks]), __builtin_bit_cast(bf16x8_t, kf), s[n], 0, 0, 0);
+      }
+    }
+    // ---- bias / masks; running max
+    float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+    bool ok[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int kj = t * BK + 16 * n + l15;
+      const float madd = (p.mask_add && kj < L) ? p.mask_add[(int64_t)b * L + kj] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q_lane0 + r;
+        const bool valid = kj < L && qi < L && !(p.causal && kj > qi);
+        float x = s[n][r] + madd;
+        if (p.bias && valid) x += p.bias[((int64_t)h * L + qi) * L + kj];
+        s[n][r] = x;
+        ok[n][r] = valid;
+        if (valid) mx[r] = fmaxf(mx[r], x);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], sh, 64));
+    }
+    float alpha[4], rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m_new = fmaxf(m_run[r], mx[r]);
+      alpha[r] = __expf(m_run[r] - m_new);
+      m_run[r] = m_new;
+      rs[r] = 0.f;
+    }
+    // ---- P = exp(S - m); row sums on the un-dropped probabilities; dropout; bf16 -> LDS [query][key]
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int kj = t * BK + 16 * n + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = ok[n][r] ? __expf(s[n][r] - m_run[r]) : 0.f;
+        rs[r] += pv;
+        if (p.drop_p > 0.f && ok[n][r]) {
+          const uint64_t gi = (((uint64_t)bh * L + (uint64_t)(q_lane0 + r)) * L) + (uint64_t)kj;
+          const uint64_t hsh = fa_mix64(seed_mix ^ (p.offset + gi));
+          pv = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? pv * inv_keep : 0.f;
+        }
+        *reinterpret_cast<uint16_t*>(Ps + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(pv);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) rs[r] += __shfl_xor(rs[r], sh, 64);
+      l_run[r] = l_run[r] * alpha[r] + rs[r];
+    }
+#pragma unroll
+    for (int i = 0; i < DN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha[r];
+    __syncthreads();                 // P tile visible (wave-private region, but the barrier is the portable ordering)
+    // ---- O += P V : A = P [16 q x 32 keys] (row reads), B = V [32 keys x 16 d] (transposing reads of the [key][d] tile)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 pf = *reinterpret_cast<const uint4*>(Ps + l15 * PPITCH + (32 * ks + 8 * g) * 2);
+      const int r0 = 32 * ks + 8 * g + tq, r1 = r0 + 4;
+#pragma unroll
+      for (int dn = 0; dn < DN; ++dn) {
+        const int colb = (16 * dn + 4 * tp) * 2;
+        const uint2 lo = lds_tr16_b64(Vs + r0 * PITCH + colb);
+        const uint2 hi = lds_tr16_b64(Vs + r1 * PITCH + colb);
+        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        oacc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, vf), oacc[dn], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- O / l, LSE
+  float* obase = p.o + b * p.o_sb + h * p.o_sh;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qi = q_lane0 + r;
+    if (qi >= L) continue;
+    const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
+#pragma unroll
+    for (int dn = 0; dn < DN; ++dn) obase[(int64_t)qi * p.o_sl + 16 * dn + l15] = oacc[dn][r] * inv;
+    if (p.lse && l15 == 0) p.lse[(int64_t)bh * L + qi] = m_run[r] + __logf(fmaxf(l_run[r], 1e-38f));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmskin_flash_attention_forward(const float* q, const float* k, const float* v, const float* mask_add, const float* bias,
+                                   float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
+                                   int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  ARG_CHECK(q && k && v && o && strides12, "flash_attention_forward: null argument");
+  ARG_CHECK(B > 0 && H > 0 && L > 0 && (Dh == 32 || Dh == 64 || Dh == 128), "flash_attention_forward: B=%d H=%d L=%d Dh=%d (Dh must be 32, 64 or 128)", B, H, L, Dh);
+  ARG_CHECK(drop_p >= 0.f && drop_p < 1.f, "flash_attention_forward: dropout %f", drop_p);
+  ARG_CHECK((int64_t)B * H <= 65535, "flash_attention_forward: B*H = %lld exceeds the grid", (long long)B * H);
+  for (int i = 0; i < 12; ++i) ARG_CHECK(strides12[i] % 4 == 0, "flash_attention_forward: stride %d = %lld is not a multiple of 4 elements (16-byte loads)", i, (long long)strides12[i]);
+  ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "flash_attention_forward: q / k / v must be 16-byte aligned");
+  FlashArgs a;
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.mask_add = mask_add; a.bias = bias;
+  a.B = B; a.H = H; a.L = L;
+  a.q_sb = strides12[0]; a.q_sh = strides12[1]; a.q_sl = strides12[2];
+  a.k_sb = strides12[3]; a.k_sh = strides12[4]; a.k_sl = strides12[5];
+  a.v_sb = strides12[6]; a.v_sh = strides12[7]; a.v_sl = strides12[8];
+  a.o_sb = strides12[9]; a.o_sh = strides12[10]; a.o_sl = strides12[11];
+  a.scale = scale; a.drop_p = drop_p; a.causal = causal; a.seed = seed; a.offset = offset;
+  const dim3 grid(ceil_div(L, 64), B * H);
+  hipStream_t st = (hipStream_t)stream;
+  if (Dh == 32) hipLaunchKernelGGL(flash_fwd_kernel<32>, grid, dim3(256), 0, st, a);
+  else if (Dh == 64) hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flash_fwd_kernel<128>, grid, dim3(256), 0, st, a);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,8 @@ Each Function allocates its outputs with torch (device memory plumbing), launche
 the HIP kernels on torch's current stream through ctypes and keeps what the
 matching backward entry point needs.  No arithmetic happens in PyTorch here.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -330,9 +332,66 @@ class LongAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, dbias, None
 
 
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def _flash_ok(q, k, v, mask_add, bias):
+    """The fused bf16 attention kernel (csrc/flash_attn.hip) serves bf16-operand mode whenever no gradient has to flow
+    through the attention (frozen encoders -- the reference's default `frozen_weights` -- and inference); trainable blocks
+    keep the unfused path, which saves the probabilities for its backward."""
+    return (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64, 128) and q.is_cuda and q.shape == k.shape == v.shape
+            and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v)))
+
+
+def _flash_forward(q, k, v, out, dims, strides, mask_add, bias, causal, p, seed, offset):
+    B, H, L, Dh = dims
+    st = (ctypes.c_int64 * 12)(*strides)
+    m = _f32c(mask_add) if mask_add is not None else None
+    bs = _f32c(bias) if bias is not None else None
+    call("mmskin_flash_attention_forward", ptr(q), ptr(k), ptr(v), ptr(m) if m is not None else None,
+         ptr(bs) if bs is not None else None, ptr(out), None, B, H, L, Dh, st, 1.0 / Dh ** 0.5, int(causal), float(p),
+         int(seed), int(offset), stream())
+    return out
+
+
+def _dropout_state(p, n):
+    if p <= 0.0:
+        return 0, 0
+    _dropout_counter[0] += n
+    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_counter[0]
+
+
+def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
+    """Attention on token-major views: q, k, v [B, L, H, Dh] (any strides with a contiguous last dim, e.g. slices of the
+    [B, L, 3, H, Dh] output of a fused qkv Linear) -> [B, L, H, Dh] contiguous.  In bf16-operand mode without gradients this
+    is ONE fused kernel reading the qkv tensor in place; otherwise the views are permuted into the [B, H, L, Dh] ops."""
+    B, L, H, Dh = q.shape
+    p = dropout_p if training else 0.0
+    if _flash_ok(q, k, v, mask_add, bias) and all(t.dtype == torch.float32 and t.data_ptr() % 16 == 0 and
+                                                   all(s % 4 == 0 for s in t.stride()[:3]) for t in (q, k, v)):
+        seed, offset = _dropout_state(p, B * H * L * L)
+        out = torch.empty((B, L, H, Dh), device=q.device, dtype=torch.float32)
+        strides = []
+        for t in (q, k, v, out):
+            strides += [t.stride(0), t.stride(2), t.stride(1)]        # (batch, head, token)
+        return _flash_forward(q, k, v, out, (B, H, L, Dh), strides, mask_add, bias, causal, p, seed, offset)
+    o = attention(q.permute(0, 2, 1, 3).contiguous(), k.permute(0, 2, 1, 3).contiguous(), v.permute(0, 2, 1, 3).contiguous(),
+                  dropout_p, training, mask_add, bias, causal)
+    return o.permute(0, 2, 1, 3).contiguous()
+
+
 def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
+    if _flash_ok(q, k, v, mask_add, bias):
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        seed, offset = _dropout_state(p, B * H * L * L)
+        out = torch.empty_like(q)
+        strides = []
+        for t in (q, k, v, out):
+            strides += [t.stride(0), t.stride(1), t.stride(2)]
+        return _flash_forward(q, k, v, out, tuple(q.shape), strides, mask_add, bias, causal, p, seed, offset)
     seed = offset = 0
     if p > 0.0:
         seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF

@@ -1,0 +1,107 @@
+"""-m gpu: the fused bf16 attention kernel (csrc/flash_attn.hip, C ABI mmskin_flash_attention_forward) against the unfused fp32
+ops (QK^T GEMM -> softmax(+bias/mask/causal) -> dropout -> PV GEMM) and against plain torch math on the CPU.  Tolerance: bf16
+operands (8 significant bits) with fp32 accumulation -- 2e-2 of the output rms; the dropout mask must be IDENTICAL to the
+unfused path's (same counter-based generator on the [B, H, L, L] element index), which is checked by comparing both with p > 0."""
+import math
+
+import pytest
+import torch
+
+from gpu_util import DEV, rel_err
+from mmskin import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    prev = ops.get_linear_dtype()
+    yield
+    ops.set_linear_dtype(prev)
+
+
+def _inputs(B, H, L, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, H, L, D, generator=g) for _ in range(3)]
+
+
+def _torch_ref(q, k, v, mask_add=None, bias=None, causal=False):
+    s = (q.double() @ k.double().transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    if bias is not None:
+        s = s + bias.double()[None]
+    if mask_add is not None:
+        s = s + mask_add.double()[:, None, None, :]
+    if causal:
+        L = q.shape[2]
+        s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+    return (torch.softmax(s, -1) @ v.double()).float()
+
+
+@pytest.mark.parametrize("B,H,L,D,kind", [(2, 4, 197, 64, "bias"), (2, 3, 512, 64, "mask"), (3, 2, 49, 32, "plain"),
+                                          (1, 2, 130, 64, "causal"), (2, 2, 77, 128, "plain"), (1, 1, 64, 64, "plain"),
+                                          (2, 2, 65, 32, "mask+causal")])
+def test_flash_forward_matches_unfused_and_torch(B, H, L, D, kind):
+    q, k, v = _inputs(B, H, L, D, L * D)
+    g = torch.Generator().manual_seed(1)
+    bias = torch.randn(H, L, L, generator=g) if "bias" in kind else None
+    mask = None
+    if "mask" in kind:
+        mask = torch.zeros(B, L)
+        mask[0, L // 2:] = -10000.0                       # BERT's extended attention mask
+        mask[-1, L - 3:] = float("-inf")
+    causal = "causal" in kind
+    want = _torch_ref(q, k, v, mask, bias, causal)
+    dev = lambda t: None if t is None else t.to(DEV)
+    with torch.no_grad():
+        ops.set_linear_dtype("fp32")
+        unfused = ops.attention(dev(q), dev(k), dev(v), mask_add=dev(mask), bias=dev(bias), causal=causal).cpu()
+        ops.set_linear_dtype("bf16")
+        fused = ops.attention(dev(q), dev(k), dev(v), mask_add=dev(mask), bias=dev(bias), causal=causal).cpu()
+    assert rel_err(unfused, want) < 1e-4
+    assert torch.isfinite(fused).all()
+    assert rel_err(fused, want) < 2e-2, rel_err(fused, want)
+
+
+def test_flash_dropout_drops_the_same_elements_as_the_unfused_path():
+    B, H, L, D = 2, 3, 200, 64
+    q, k, v = (t.to(DEV) for t in _inputs(B, H, L, D, 9))
+    outs = {}
+    with torch.no_grad():
+        for mode in ("fp32", "bf16"):
+            ops.set_linear_dtype(mode)
+            torch.manual_seed(1234)
+            ops._dropout_counter[0] = 1000                 # same generator position for both calls
+            outs[mode] = ops.attention(q, k, v, 0.3, True).cpu()
+        ops.set_linear_dtype("bf16")
+        torch.manual_seed(1234)
+        ops._dropout_counter[0] = 77777
+        other = ops.attention(q, k, v, 0.3, True).cpu()
+        nodrop = ops.attention(q, k, v, 0.0, True).cpu()
+    assert rel_err(outs["bf16"], outs["fp32"]) < 2e-2      # identical mask, bf16 operands
+    assert rel_err(other, outs["fp32"]) > 0.2               # another generator position gives another mask
+    assert rel_err(nodrop, outs["fp32"]) > 0.2
+
+
+def test_flash_reads_a_fused_qkv_tensor_in_place():
+    """attention_blhd on slices of the [B, L, 3, H, Dh] output of a qkv Linear: no permute copies, token-major output."""
+    B, L, H, D = 3, 197, 4, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, L, 3, H, D, generator=g)
+    want = _torch_ref(*(qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))).permute(0, 2, 1, 3)
+    qd = qkv.to(DEV)
+    with torch.no_grad():
+        ops.set_linear_dtype("bf16")
+        got = ops.attention_blhd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2])
+        assert got.shape == (B, L, H, D) and got.is_contiguous()
+        assert rel_err(got.cpu(), want) < 2e-2
+        ops.set_linear_dtype("fp32")                                        # unfused fallback of the same entry
+        assert rel_err(ops.attention_blhd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2]).cpu(), want) < 1e-4
+
+
+def test_trainable_attention_keeps_the_differentiable_path():
+    """Gradients must keep flowing: with requires_grad inputs bf16 mode uses the unfused ops (which save the probabilities)."""
+    ops.set_linear_dtype("bf16")
+    q, k, v = (t.to(DEV).requires_grad_(True) for t in _inputs(1, 2, 70, 64, 3))
+    o = ops.attention(q, k, v)
+    o.sum().backward()
+    assert q.grad is not None and torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0
