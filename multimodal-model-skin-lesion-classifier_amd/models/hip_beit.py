@@ -67,10 +67,10 @@ class _Attention(nn.Module):
         H = self.num_heads
         E = x.shape[1]
         bias = torch.cat([self.q_bias, self.k_bias, self.v_bias])
-        qkv = ops.linear(x, self.qkv.weight, bias).reshape(B, L, 3, H, E // H).permute(2, 0, 3, 1, 4).contiguous()
+        qkv = ops.linear(x, self.qkv.weight, bias).reshape(B, L, 3, H, E // H)
         rel = self.relative_position_bias_table[self.relative_position_index.reshape(-1)].reshape(L, L, H).permute(2, 0, 1).contiguous()
-        o = ops.attention(qkv[0], qkv[1], qkv[2], bias=rel)
-        return self.proj(o.permute(0, 2, 1, 3).reshape(B * L, E))
+        o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=rel)      # token-major views of the fused qkv output
+        return self.proj(o.reshape(B * L, E))
 
 
 class _Mlp(nn.Module):

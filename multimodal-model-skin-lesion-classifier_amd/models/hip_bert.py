@@ -65,10 +65,10 @@ class _SelfAttention(nn.Module):
     def forward(self, x, B, L, mask_add):
         H = self.num_attention_heads
         E = x.shape[1]
-        split = lambda t: t.reshape(B, L, H, E // H).permute(0, 2, 1, 3).contiguous()
-        o = ops.attention(split(self.query(x)), split(self.key(x)), split(self.value(x)), self.dropout.p, self.training,
-                          mask_add=mask_add)
-        return o.permute(0, 2, 1, 3).reshape(B * L, E)
+        split = lambda t: t.reshape(B, L, H, E // H)                                   # token-major: no permute copies
+        o = ops.attention_blhd(split(self.query(x)), split(self.key(x)), split(self.value(x)), self.dropout.p, self.training,
+                               mask_add=mask_add)
+        return o.reshape(B * L, E)
 
 
 class _SelfOutput(nn.Module):

@@ -67,9 +67,9 @@ class _WindowAttention(nn.Module):
     def forward(self, xw):            # [nW*B, 49, C]
         Bw, L, C = xw.shape
         H = self.num_heads
-        qkv = self.qkv(xw.reshape(Bw * L, C)).reshape(Bw, L, 3, H, C // H).permute(2, 0, 3, 1, 4).contiguous()
-        o = ops.attention(qkv[0], qkv[1], qkv[2])
-        return self.proj(o.permute(0, 2, 1, 3).reshape(Bw * L, C)).reshape(Bw, L, C)
+        qkv = self.qkv(xw.reshape(Bw * L, C)).reshape(Bw, L, 3, H, C // H)
+        o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+        return self.proj(o.reshape(Bw * L, C)).reshape(Bw, L, C)
 
 
 class _ChannelAttention(nn.Module):

@@ -54,9 +54,10 @@ class _Attention(nn.Module):
 
     def forward(self, x, B, L, mask_add):
         H, E = self.num_heads, x.shape[1]
-        qkv = self.c_attn(x).reshape(B, L, 3, H, E // H).permute(2, 0, 3, 1, 4).contiguous()
-        o = ops.attention(qkv[0], qkv[1], qkv[2], self.attn_dropout.p, self.training, mask_add=mask_add, causal=True)
-        return self.resid_dropout(self.c_proj(o.permute(0, 2, 1, 3).reshape(B * L, E)))
+        qkv = self.c_attn(x).reshape(B, L, 3, H, E // H)
+        o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.attn_dropout.p, self.training, mask_add=mask_add,
+                               causal=True)
+        return self.resid_dropout(self.c_proj(o.reshape(B * L, E)))
 
 
 class _MLP(nn.Module):

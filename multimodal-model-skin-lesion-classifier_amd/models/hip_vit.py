@@ -59,9 +59,9 @@ class _Attention(nn.Module):
     def forward(self, x, B, L):
         H = self.num_heads
         E = x.shape[1]
-        qkv = self.qkv(x).reshape(B, L, 3, H, E // H).permute(2, 0, 3, 1, 4).contiguous()      # [3, B, H, L, Dh]
-        o = ops.attention(qkv[0], qkv[1], qkv[2])
-        return self.proj(o.permute(0, 2, 1, 3).reshape(B * L, E))
+        qkv = self.qkv(x).reshape(B, L, 3, H, E // H)                                           # token-major: read in place
+        o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+        return self.proj(o.reshape(B * L, E))
 
 
 class _Mlp(nn.Module):
