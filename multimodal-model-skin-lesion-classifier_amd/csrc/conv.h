@@ -39,7 +39,8 @@ struct ConvGemmArgs {
   const float* ep_scale;   // with ep_shift: mask = (ep_x*scale + shift > 0)   (plain BN+ReLU)
   const float* ep_shift;
   const float* ep_bias;    // inference: per-output-channel constant added to acc (+ addend) -- the folded BatchNorm shift
-  int ep_relu;             // inference: ReLU on the stored value
+  int ep_relu;             // 1: ReLU on the stored value (folded-BN inference, Linear + ReLU); 2: exact GELU (transformer MLPs)
+  float* out_f32;          // light-epilogue launches only: store the tile as fp32 HERE instead of T at `out` (Linear ops at the fp32 boundary)
   const void* ep_x2;       // second raw tensor (downsample BN of the same block) -> stat_b_*
   float* stat_b_sum;       // = sum v   (again, so the downsample finalize sees the same slab layout)
   float* stat_b_sq;        // = sum v*ep_x2
@@ -74,6 +75,8 @@ struct FwdFuse {
   const float* bias = nullptr;    // [Cout] fp32
   const void* addend = nullptr;   // optional residual, same layout as out
   bool relu = false;
+  bool gelu = false;              // exact GELU instead of ReLU
+  float* out_f32 = nullptr;       // write the result as fp32 here (the T output pointer is then unused)
 };
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,

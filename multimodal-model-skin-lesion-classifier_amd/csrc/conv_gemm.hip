@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   const unsigned char* ex2_b = HAS_X2 ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
   const bool mask_from_x = HAS_X && p.ep_scale != nullptr;
   const bool has_bias = HAS_BR && p.ep_bias != nullptr;
-  const bool do_relu = HAS_BR && p.ep_relu;
+  const bool do_relu = HAS_BR && p.ep_relu == 1;
+  const bool do_gelu = HAS_BR && p.ep_relu == 2;          // exact (erf) GELU: the MLP of the transformer blocks
+  float* out_f32 = HAS_BR ? p.out_f32 : nullptr;         // Linear layers at the fp32 op boundary: widen while storing
   float ebias[EPC];
   if (has_bias) {
 #pragma unroll
@@ -321,6 +323,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v.v[e] = fmaxf(v.v[e], 0.f);
       }
+      if (do_gelu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v.v[e] = 0.5f * v.v[e] * (1.f + erff(v.v[e] * 0.70710678118654752f));
+      }
       if (my_b) {
         Chunk<T> my;
         my.from_raw(q_my[k]);
@@ -356,7 +362,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
       }
-      if (!(abl & 8)) v.store(out_b + goffs[k]);
+      if (out_f32) {
+        float* dst = out_f32 + goffs[k] / sizeof(T);
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(v.v[e], v.v[e + 1], v.v[e + 2], v.v[e + 3]);
+      } else if (!(abl & 8)) v.store(out_b + goffs[k]);
     }
   }
   if (p.stat_sum) {
@@ -416,7 +426,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
 #ifdef MMSKIN_ABLATE
   { const char* abl = getenv("MMSKIN_CONV_ABLATE"); a.ablate = abl ? atoi(abl) : 0; }
 #endif
-  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu;
+  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
@@ -461,7 +471,7 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
-  if (fuse) { a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->relu ? 1 : 0; }
+  if (fuse) { a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->gelu ? 2 : (fuse->relu ? 1 : 0); a.out_f32 = fuse->out_f32; }
   a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
   a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;

@@ -803,25 +803,30 @@ extern "C" {
 int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
                           void* stream) {
   ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+  ARG_CHECK(relu >= 0 && relu <= 2, "linear_forward: activation %d (0 none, 1 ReLU, 2 exact GELU)", relu);
   if (linear_big(M, K, N) && linear_bf16()) {
+    // bf16 operands, fp32 accumulate; bias + activation + the widening to fp32 all happen in the GEMM epilogue
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
-    const size_t xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256), yb = align_up((size_t)M * N * 2, 256);
-    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb + yb));
+    const size_t xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb));
     if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
-    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
+    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb);
     int rc;
     if ((rc = cvt_to_bf16(x, x16, (int64_t)M * K, ST(stream)))) return rc;
     if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, ST(stream)))) return rc;
-    FwdFuse f; f.bias = b; f.relu = relu != 0;
-    if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, y16, nullptr, nullptr, ST(stream), (b || relu) ? &f : nullptr))) return rc;
-    return cvt_to_f32(y16, y, (int64_t)M * N, ST(stream));
+    FwdFuse f; f.bias = b; f.relu = relu == 1; f.gelu = relu == 2; f.out_f32 = y;
+    return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, ST(stream), &f);
   }
   if (linear_big(M, K, N)) {   // tokens x hidden GEMMs of the text encoders: the exact-f32 implicit-GEMM kernel as a 1x1 conv
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
-    FwdFuse f; f.bias = b; f.relu = relu != 0;
+    FwdFuse f; f.bias = b; f.relu = relu == 1; f.gelu = relu == 2;
     return launch_conv_fwd<float>(s, x, w, y, nullptr, nullptr, ST(stream), (b || relu) ? &f : nullptr);
   }
-  return gemm_f32(x, w, y, b, M, N, K, K, 1, K, 1, N, relu, ST(stream));
+  int rc = gemm_f32(x, w, y, b, M, N, K, K, 1, K, 1, N, relu == 1, ST(stream));
+  if (rc || relu != 2) return rc;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, ST(stream), y, y, (int64_t)M * N);   // in place: element i only
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
 }
 
 int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,

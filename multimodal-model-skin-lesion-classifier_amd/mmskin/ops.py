@@ -610,6 +610,16 @@ class GeluFn(torch.autograd.Function):
 gelu = GeluFn.apply
 
 
+def linear_gelu(x, w, b=None):
+    """gelu(x @ w.T + b) -- the first half of a transformer MLP.  Without gradients (frozen encoders, inference) bias and the
+    exact GELU run in the GEMM epilogue (one launch, the pre-activation never reaches memory); with gradients the two ops
+    stay separate because GELU's backward needs the pre-activation."""
+    if _needs_grad(x, w, b):
+        return gelu(linear(x, w, b))
+    with torch.no_grad():
+        return LinearFn.apply(x, w, b, 2)
+
+
 @no_second_order
 class GeluTanhFn(torch.autograd.Function):
     @staticmethod

@@ -105,7 +105,7 @@ class _Layer(nn.Module):
 
     def forward(self, x, B, L, mask_add):
         a = self.attention.output(self.attention.self(x, B, L, mask_add), x)
-        return self.output(ops.gelu(self.intermediate.dense(a)), a)
+        return self.output(ops.linear_gelu(a, self.intermediate.dense.weight, self.intermediate.dense.bias), a)
 
 
 class _Encoder(nn.Module):

@@ -54,7 +54,7 @@ class _Mlp(nn.Module):
         self.fc2 = HipLinear(dim * 4, dim)
 
     def forward(self, x):
-        return self.fc2(ops.gelu(self.fc1(x)))
+        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias))
 
 
 class _WindowAttention(nn.Module):

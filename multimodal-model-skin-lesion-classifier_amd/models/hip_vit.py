@@ -72,7 +72,7 @@ class _Mlp(nn.Module):
         self.fc2 = HipLinear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(ops.gelu(self.fc1(x)))
+        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias))
 
 
 class _Block(nn.Module):

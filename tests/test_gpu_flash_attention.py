@@ -130,3 +130,25 @@ def test_trainable_attention_keeps_the_differentiable_path():
     o = ops.attention(q, k, v)
     o.sum().backward()
     assert q.grad is not None and torch.isfinite(q.grad).all() and float(q.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 256, 512), (2500, 128, 64), (64, 96, 40)])
+def test_linear_gelu_epilogue(M, K, N):
+    """gelu(x W^T + b) fused into the GEMM epilogue (no-grad path) = the separate ops, in both operand modes and on the small
+    fp32 GEMM path; with gradients the unfused pair runs and differentiates."""
+    g = torch.Generator().manual_seed(M)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    want = torch.nn.functional.gelu(x.double() @ w.double().T + b.double()).float()
+    for mode, tol in (("fp32", 1e-4), ("bf16", 3e-2)):
+        ops.set_linear_dtype(mode)
+        with torch.no_grad():
+            fused = ops.linear_gelu(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+            pair = ops.gelu(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV))).cpu()
+        assert rel_err(fused, want) < tol, (mode, rel_err(fused, want))
+        assert rel_err(fused, pair) < (1e-5 if mode == "fp32" else 1e-2)     # bf16: the unfused pair rounds the pre-activation to bf16 too
+    ops.set_linear_dtype("fp32")
+    xg = x.to(DEV).requires_grad_(True)
+    ops.linear_gelu(xg, w.to(DEV), b.to(DEV)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xr @ w.T + b).sum().backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-3
