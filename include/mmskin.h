@@ -208,7 +208,7 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
  * fused qkv Linear is read in place.  mask_add [B][L] additive key mask or NULL; bias [H][L][L] additive score bias or NULL
  * (BEiT's relative-position bias); causal != 0: key j > query i masked; drop_p: dropout on the probabilities with the library's
  * counter-based generator on the element index of the [B, H, L, L] tensor (seed, offset as mmskin_dropout_forward);
- * lse (optional) [B][H][L] = log-sum-exp of the scaled, biased scores.  Dh in {32, 64, 128}. */
+ * lse (optional) [B][H][L] = log-sum-exp of the scaled, biased scores.  Dh in {32, 64}. */
 int mmskin_flash_attention_forward(const float* q, const float* k, const float* v, const float* mask_add, const float* bias,
                                    float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
                                    int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);

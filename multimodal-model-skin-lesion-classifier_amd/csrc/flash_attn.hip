@@ -56,12 +56,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   constexpr int KS = D / 32;                 // k-steps of the QK^T product
   constexpr int DN = D / 16;                 // 16-wide output column tiles
   constexpr int CPT = BK * (D / 4) / 256;    // float4 chunks per thread per tile (K and V each)
-  static_assert(D == 32 || D == 64 || D == 128, "head dim");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BK * PITCH + 4 * 16 * PPITCH];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + BK * PITCH;
+  static_assert(D == 32 || D == 64, "head dim");
+  constexpr int KV_BYTES = 2 * BK * PITCH;   // one K tile + one V tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BYTES + 4 * 16 * PPITCH];   // K / V double-buffered
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  unsigned char* Ps = smem + 2 * BK * PITCH + wid * 16 * PPITCH;
+  unsigned char* Ps = smem + 2 * KV_BYTES + wid * 16 * PPITCH;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * BQ;
   const int L = p.L;
@@ -108,12 +107,14 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    unsigned char* Kd = smem + buf * KV_BYTES;
+    unsigned char* Vd = Kd + BK * PITCH;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
       const int c = tid + 256 * i, key = c / (D / 4), dc = c - key * (D / 4);
-      *reinterpret_cast<uint2*>(Ks + key * PITCH + dc * 8) = make_uint2(pack_bf16(kr[i].x, kr[i].y), pack_bf16(kr[i].z, kr[i].w));
-      *reinterpret_cast<uint2*>(Vs + key * PITCH + dc * 8) = make_uint2(pack_bf16(vr[i].x, vr[i].y), pack_bf16(vr[i].z, vr[i].w));
+      *reinterpret_cast<uint2*>(Kd + key * PITCH + dc * 8) = make_uint2(pack_bf16(kr[i].x, kr[i].y), pack_bf16(kr[i].z, kr[i].w));
+      *reinterpret_cast<uint2*>(Vd + key * PITCH + dc * 8) = make_uint2(pack_bf16(vr[i].x, vr[i].y), pack_bf16(vr[i].z, vr[i].w));
     }
   };
 
@@ -122,11 +123,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   const int q_lane0 = q0 + wid * 16 + 4 * g;      // first of this lane's 4 query rows
   const int tq = l15 >> 2, tp = l15 & 3;          // transposing-read roles inside a 16-lane group
 
-  if (nt > 0) load_tile(0);
+  // ONE barrier per key tile: tile t+1 is fetched into registers while tile t is multiplied and lands in the OTHER LDS buffer
+  // (last read in iteration t-1, which every wave has left through the barrier that ended it).
+  if (nt > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();                 // every wave is done with the previous tile's K / V (and P)
-    store_tile();
-    __syncthreads();
+    const unsigned char* Ks = smem + (t & 1) * KV_BYTES;
+    const unsigned char* Vs = Ks + BK * PITCH;
     if (t + 1 < nt) load_tile(t + 1);   // in flight under this tile's MFMAs
 
     // ---- S = (scale Q) K^T : 4 key groups of 16
@@ -197,7 +200,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
     for (int i = 0; i < DN; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha[r];
-    __syncthreads();                 // P tile visible (wave-private region, but the barrier is the portable ordering)
+    // The P tile is wave-private and DS instructions of one wave execute in order: the reads below see the writes above
+    // without a workgroup barrier (the compiler keeps the order: same LDS array).
     // ---- O += P V : A = P [16 q x 32 keys] (row reads), B = V [32 keys x 16 d] (transposing reads of the [key][d] tile)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -212,6 +216,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
         oacc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, vf), oacc[dn], 0, 0, 0);
       }
     }
+    if (t + 1 < nt) store_tile((t + 1) & 1);
+    __syncthreads();
   }
 
   // ---- O / l, LSE
@@ -235,7 +241,7 @@ int mmskin_flash_attention_forward(const float* q, const float* k, const float* 
                                    float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
                                    int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
   ARG_CHECK(q && k && v && o && strides12, "flash_attention_forward: null argument");
-  ARG_CHECK(B > 0 && H > 0 && L > 0 && (Dh == 32 || Dh == 64 || Dh == 128), "flash_attention_forward: B=%d H=%d L=%d Dh=%d (Dh must be 32, 64 or 128)", B, H, L, Dh);
+  ARG_CHECK(B > 0 && H > 0 && L > 0 && (Dh == 32 || Dh == 64), "flash_attention_forward: B=%d H=%d L=%d Dh=%d (Dh must be 32 or 64)", B, H, L, Dh);
   ARG_CHECK(drop_p >= 0.f && drop_p < 1.f, "flash_attention_forward: dropout %f", drop_p);
   ARG_CHECK((int64_t)B * H <= 65535, "flash_attention_forward: B*H = %lld exceeds the grid", (long long)B * H);
   for (int i = 0; i < 12; ++i) ARG_CHECK(strides12[i] % 4 == 0, "flash_attention_forward: stride %d = %lld is not a multiple of 4 elements (16-byte loads)", i, (long long)strides12[i]);
@@ -251,8 +257,7 @@ int mmskin_flash_attention_forward(const float* q, const float* k, const float* 
   const dim3 grid(ceil_div(L, 64), B * H);
   hipStream_t st = (hipStream_t)stream;
   if (Dh == 32) hipLaunchKernelGGL(flash_fwd_kernel<32>, grid, dim3(256), 0, st, a);
-  else if (Dh == 64) hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(flash_fwd_kernel<128>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 0, st, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -340,7 +340,7 @@ def _flash_ok(q, k, v, mask_add, bias):
     """The fused bf16 attention kernel (csrc/flash_attn.hip) serves bf16-operand mode whenever no gradient has to flow
     through the attention (frozen encoders -- the reference's default `frozen_weights` -- and inference); trainable blocks
     keep the unfused path, which saves the probabilities for its backward."""
-    return (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64, 128) and q.is_cuda and q.shape == k.shape == v.shape
+    return (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64) and q.is_cuda and q.shape == k.shape == v.shape
             and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v)))
 
 
