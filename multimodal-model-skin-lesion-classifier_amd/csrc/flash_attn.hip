@@ -20,6 +20,8 @@
 //     place and O can be written token-major, without permute copies
 // fp32 tensors at the boundary (the host ops are fp32), fp32 accumulation and softmax; LSE is written for a backward pass.
 #include "../../include/mmskin.h"
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -48,7 +50,7 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
 }
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
 
-template <int D>
+template <int D, int NB>   // NB = LDS buffers for the K / V tiles (1: two barriers per key tile; 2: one)
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   constexpr int BQ = 64, BK = 64;
   constexpr int PITCH = D * 2 + 16;          // bytes per K / V row in LDS
@@ -58,9 +60,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   constexpr int CPT = BK * (D / 4) / 256;    // float4 chunks per thread per tile (K and V each)
   static_assert(D == 32 || D == 64, "head dim");
   constexpr int KV_BYTES = 2 * BK * PITCH;   // one K tile + one V tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BYTES + 4 * 16 * PPITCH];   // K / V double-buffered
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NB * KV_BYTES + 4 * 16 * PPITCH];
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
-  unsigned char* Ps = smem + 2 * KV_BYTES + wid * 16 * PPITCH;
+  unsigned char* Ps = smem + NB * KV_BYTES + wid * 16 * PPITCH;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * BQ;
   const int L = p.L;
@@ -128,9 +130,22 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   if (nt > 0) { load_tile(0); store_tile(0); }
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const unsigned char* Ks = smem + (t & 1) * KV_BYTES;
+    const unsigned char* Ks = smem + (NB == 2 ? (t & 1) : 0) * KV_BYTES;
     const unsigned char* Vs = Ks + BK * PITCH;
-    if (t + 1 < nt) load_tile(t + 1);   // in flight under this tile's MFMAs
+    // Score addends of THIS tile first: vmcnt retires in issue order, so a wait for these (younger) loads would otherwise also
+    // drain the next tile's K / V prefetch issued below and serialise it with the softmax.
+    float madd[4], badd[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int kj = t * BK + 16 * n + l15;
+      madd[n] = (p.mask_add && kj < L) ? p.mask_add[(int64_t)b * L + kj] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = q_lane0 + r;
+        badd[n][r] = (p.bias && kj < L && qi < L) ? p.bias[((int64_t)h * L + qi) * L + kj] : 0.f;
+      }
+    }
+    if (t + 1 < nt) load_tile(t + 1);   // in flight under this tile's MFMAs and softmax
 
     // ---- S = (scale Q) K^T : 4 key groups of 16
     f32x4_t s[4];
@@ -149,13 +164,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const int kj = t * BK + 16 * n + l15;
-      const float madd = (p.mask_add && kj < L) ? p.mask_add[(int64_t)b * L + kj] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = q_lane0 + r;
         const bool valid = kj < L && qi < L && !(p.causal && kj > qi);
-        float x = s[n][r] + madd;
-        if (p.bias && valid) x += p.bias[((int64_t)h * L + qi) * L + kj];
+        const float x = s[n][r] + madd[n] + badd[n][r];
         s[n][r] = x;
         ok[n][r] = valid;
         if (valid) mx[r] = fmaxf(mx[r], x);
@@ -216,8 +229,14 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
         oacc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, vf), oacc[dn], 0, 0, 0);
       }
     }
-    if (t + 1 < nt) store_tile((t + 1) & 1);
-    __syncthreads();
+    if constexpr (NB == 2) {
+      if (t + 1 < nt) store_tile((t + 1) & 1);
+      __syncthreads();
+    } else {
+      __syncthreads();                       // every wave is done with this tile's K / V
+      if (t + 1 < nt) store_tile(0);
+      __syncthreads();
+    }
   }
 
   // ---- O / l, LSE
@@ -256,8 +275,9 @@ int mmskin_flash_attention_forward(const float* q, const float* k, const float* 
   a.scale = scale; a.drop_p = drop_p; a.causal = causal; a.seed = seed; a.offset = offset;
   const dim3 grid(ceil_div(L, 64), B * H);
   hipStream_t st = (hipStream_t)stream;
-  if (Dh == 32) hipLaunchKernelGGL(flash_fwd_kernel<32>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 0, st, a);
+  static const int nb = [] { const char* e = getenv("MMSKIN_FLASH_BUFFERS"); return e ? atoi(e) : 2; }();
+  if (Dh == 32) { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<32, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<32, 2>), grid, dim3(256), 0, st, a); }
+  else { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<64, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<64, 2>), grid, dim3(256), 0, st, a); }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
