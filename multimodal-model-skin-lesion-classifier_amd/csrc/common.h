@@ -75,6 +75,15 @@ template <> struct Chunk<float> {
   __device__ __forceinline__ void store(void* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  // streamed-once variants (nontemporal cache policy): keep L2 / Infinity Cache for data that is re-read
+  __device__ __forceinline__ void load_nt(const void* p) {
+    u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    from_raw(t);
+  }
+  __device__ __forceinline__ void store_nt(void* p) const {
+    u32x4_t t = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+  }
 };
 template <> struct Chunk<bf16_t> {
   float v[8];
@@ -99,6 +108,16 @@ template <> struct Chunk<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __device__ __forceinline__ void load_nt(const void* p) {
+    u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    from_raw(t);
+  }
+  __device__ __forceinline__ void store_nt(void* p) const {
+    u32x4_t t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = f32_to_bf16_bits(v[2 * i]) | (f32_to_bf16_bits(v[2 * i + 1]) << 16);
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
   }
 };
 

@@ -1,6 +1,8 @@
 // HBM-bound NHWC kernels (see ops.h).  Replaces the ATen batch_norm / relu / add / max_pool2d /
 // adaptive_avg_pool2d forward+backward kernels the reference reaches through torchvision's ResNet
 // (multimodalIntraInterModal.py:167).
+#include <stdlib.h>
+
 #include "ops.h"
 
 #define EW_BLOCK 256
@@ -230,7 +232,7 @@ int bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* ru
   return MMSKIN_OK;
 }
 
-template <typename T, int RELU, int RES>  // RELU: 0 none, 1 relu / capped relu, 2 SiLU; RES: 0 none, 1 plain residual, 2 residual*rscale + rshift
+template <typename T, int RELU, int RES, bool NT = false>  // RELU: 0 none, 1 relu / capped relu, 2 SiLU; RES: 0 none, 1 plain residual, 2 residual*rscale + rshift
 __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -242,9 +244,9 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_apply_kernel(const T* __restrict_
   for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
     int c0 = (int)(i % CPR) * EPC;
     Chunk<T> v;
-    v.load(x + i * EPC);
+    if (NT) v.load_nt(x + i * EPC); else v.load(x + i * EPC);     // the raw conv output is read once more only in backward
     Chunk<T> r;
-    if (RES) r.load(res + i * EPC);
+    if (RES) { if (NT) r.load_nt(res + i * EPC); else r.load(res + i * EPC); }
     uint32_t bits = 0;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -274,7 +276,13 @@ int bn_apply(const T* x, const T* res, const float* scale, const float* shift, c
   int mode = res ? (rscale ? 2 : 1) : 0;
 #define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC, relu_cap)
   if (relu && relu_cap < 0.f) { if (mode == 2) LAUNCH(2, 2); else if (mode == 1) LAUNCH(2, 1); else LAUNCH(2, 0); }
-  else if (relu) { if (mode == 2) LAUNCH(1, 2); else if (mode == 1) LAUNCH(1, 1); else LAUNCH(1, 0); }
+  else if (relu) {
+    static const bool nt = [] { const char* v = getenv("MMSKIN_EW_NT"); return !v || atoi(v) != 0; }();
+#define LAUNCH_NT(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H, true>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC, relu_cap)
+    if (nt) { if (mode == 2) LAUNCH_NT(1, 2); else if (mode == 1) LAUNCH_NT(1, 1); else LAUNCH_NT(1, 0); }
+    else { if (mode == 2) LAUNCH(1, 2); else if (mode == 1) LAUNCH(1, 1); else LAUNCH(1, 0); }
+#undef LAUNCH_NT
+  }
   else { if (mode == 2) LAUNCH(0, 2); else if (mode == 1) LAUNCH(0, 1); else LAUNCH(0, 0); }
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
@@ -453,7 +461,7 @@ int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const 
   return MMSKIN_OK;
 }
 
-template <typename T, int MODE, bool WRITE_DZ>
+template <typename T, int MODE, bool WRITE_DZ, bool NT = false>
 __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ ymask,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ cA,
@@ -464,8 +472,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bn_bwd_apply_kernel(
     const int c0 = (int)(i % CPR) * EPC;
     const size_t off = i * EPC;
     Chunk<T> dz, xv;
-    dz.load(dy + off);
-    xv.load(x + off);
+    if (NT) { dz.load_nt(dy + off); xv.load_nt(x + off); } else { dz.load(dy + off); xv.load(x + off); }
     masked_dy<T, MODE>(dz, xv, ymask, off, scale, shift, c0);
     if (WRITE_DZ) dz.store(dz_out + off);
 #pragma unroll
@@ -487,7 +494,14 @@ int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, co
   else if (mask_mode == MASK_FROM_Y) { if (dz_out) LAUNCH(MASK_FROM_Y, true); else LAUNCH(MASK_FROM_Y, false); }
   else if (mask_mode == MASK_FROM_Y6) { if (dz_out) LAUNCH(MASK_FROM_Y6, true); else LAUNCH(MASK_FROM_Y6, false); }
   else if (mask_mode == MASK_SILU_X) { if (dz_out) LAUNCH(MASK_SILU_X, true); else LAUNCH(MASK_SILU_X, false); }
-  else { if (dz_out) LAUNCH(MASK_NONE, true); else LAUNCH(MASK_NONE, false); }
+  else {
+    // nontemporal loads of dz / x (each is read for the last time here; dx stays cacheable: the dgrad and the weight-gradient
+    // GEMM read it next): same-box A/B 20.74 -> 20.43 ms per step (MMSKIN_EW_NT=0/1, profiles/r02_experiments.txt)
+    static const bool nt = [] { const char* v = getenv("MMSKIN_EW_NT"); return !v || atoi(v) != 0; }();
+    if (dz_out) LAUNCH(MASK_NONE, true);
+    else if (nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MASK_NONE, false, true>), dim3(grid), dim3(EW_BLOCK), 0, st, dy, x, ymask, scale, shift, cA, cB, cC, dx, dz_out, nch, C / EPC);
+    else LAUNCH(MASK_NONE, false);
+  }
 #undef LAUNCH
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
