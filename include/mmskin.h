@@ -203,15 +203,24 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
 /* Fused attention, bf16 MFMA with fp32 accumulation / softmax / I/O:  o = dropout(softmax(q k^T * scale + bias + mask)) v  in one
  * kernel; the [B, H, L, L] scores never reach memory.  Replaces the QK^T GEMM -> softmax -> dropout -> PV GEMM chain of the
  * transformer encoders (timm ViT / BEiT blocks, transformers' BertSelfAttention / GPT2Attention; loadImageModelClassifier.py
- * :117-121, :170-181) in bf16-operand mode.  q, k, v, o: fp32, element (b, h, l, d) at ptr + b*sb + h*sh + l*sl + d, the twelve
- * strides given as strides12 = {q_sb, q_sh, q_sl, k_*, v_*, o_*} (multiples of 4; pointers 16-byte aligned), so the output of a
+ * :117-121, :170-181) in bf16-operand mode.  q, k, v, o: io_dtype (MMSKIN_F32 or MMSKIN_BF16), element (b, h, l, d) at index b*sb + h*sh + l*sl + d, the twelve
+ * ELEMENT strides given as strides12 = {q_sb, q_sh, q_sl, k_*, v_*, o_*} (q / k / v: multiples of 16 bytes; pointers 16-byte aligned), so the output of a
  * fused qkv Linear is read in place.  mask_add [B][L] additive key mask or NULL; bias [H][L][L] additive score bias or NULL
  * (BEiT's relative-position bias); causal != 0: key j > query i masked; drop_p: dropout on the probabilities with the library's
  * counter-based generator on the element index of the [B, H, L, L] tensor (seed, offset as mmskin_dropout_forward);
  * lse (optional) [B][H][L] = log-sum-exp of the scaled, biased scores.  Dh in {32, 64}. */
-int mmskin_flash_attention_forward(const float* q, const float* k, const float* v, const float* mask_add, const float* bias,
-                                   float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
-                                   int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, const float* mask_add, const float* bias,
+                                   void* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, int io_dtype,
+                                   float scale, int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+/* Inference lane of the transformer encoders in bf16-operand mode (no gradient flows: frozen encoders, evaluation): activations pass
+ * between layers as bf16, so no fp32 <-> bf16 conversion passes run.  linear_forward_ex: x [M][K] and y [M][N] are fp32
+ * (dtype MMSKIN_F32) or bf16 (MMSKIN_BF16) independently; w [N][K], b [N] fp32; act 0 none / 1 ReLU / 2 exact GELU, fused into the GEMM
+ * epilogue; shapes off the large-GEMM path are computed through the fp32 entry point.  layernorm_forward_mixed: nn.LayerNorm with the
+ * result written as fp32 (y_f32) and / or bf16 (y_bf16); N % 4 == 0, N <= 2048. */
+int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, int M, int K, int N,
+                             int act, void* stream);
+int mmskin_layernorm_forward_mixed(const float* x, const float* g, const float* b, float* y_f32, void* y_bf16, int M, int N,
+                                   float eps, void* stream);
 /* Operand type of the large Linear GEMMs (rows >= 2048, 64-multiple widths: the transformer backbones' and BERT's
  * projections): MMSKIN_F32 = exact-f32 MFMA (default, parity mode), MMSKIN_BF16 = bf16 operands with fp32 accumulation
  * (BASELINE configs[3] is quoted in bf16).  Process-wide; the environment variable MMSKIN_LINEAR_DTYPE sets the initial value. */

@@ -18,7 +18,8 @@
 //     a fused launch drops exactly the elements the unfused path would
 //   * q / k / v / o are addressed through element strides: the [B, L, 3, H, Dh] output of a fused qkv Linear is read in
 //     place and O can be written token-major, without permute copies
-// fp32 tensors at the boundary (the host ops are fp32), fp32 accumulation and softmax; LSE is written for a backward pass.
+// fp32 or bf16 tensors at the boundary (io_dtype; fp32 inputs are rounded to bf16 on arrival), fp32 accumulation and softmax; LSE is
+// written for a backward pass.
 #include "../../include/mmskin.h"
 #include <stdlib.h>
 
@@ -27,8 +28,8 @@
 namespace {
 
 struct FlashArgs {
-  const float* q; const float* k; const float* v;
-  float* o; float* lse;
+  const void* q; const void* k; const void* v;   // IO = float or bf16_t (template parameter of the kernel)
+  void* o; float* lse;
   const float* mask_add;   // [B][L] additive key mask or null
   const float* bias;       // [H][L][L] additive score bias or null
   int B, H, L;
@@ -50,14 +51,21 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
 }
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16); }
 
-template <int D, int NB>   // NB = LDS buffers for the K / V tiles (1: two barriers per key tile; 2: one)
+// 8 consecutive elements of one row as a packed bf16x8 MFMA fragment / LDS chunk
+__device__ __forceinline__ uint4 load8_bf16(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+  return make_uint4(pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(c.x, c.y), pack_bf16(c.z, c.w));
+}
+__device__ __forceinline__ uint4 load8_bf16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <int D, int NB, typename IO>   // NB = LDS buffers for the K / V tiles (1: two barriers per key tile; 2: one); IO = tensor dtype
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   constexpr int BQ = 64, BK = 64;
   constexpr int PITCH = D * 2 + 16;          // bytes per K / V row in LDS
   constexpr int PPITCH = BK * 2 + 16;        // bytes per P row
   constexpr int KS = D / 32;                 // k-steps of the QK^T product
   constexpr int DN = D / 16;                 // 16-wide output column tiles
-  constexpr int CPT = BK * (D / 4) / 256;    // float4 chunks per thread per tile (K and V each)
+  constexpr int CPT = BK * (D / 8) / 256;    // 8-element chunks per thread per tile (K and V each)
   static_assert(D == 32 || D == 64, "head dim");
   constexpr int KV_BYTES = 2 * BK * PITCH;   // one K tile + one V tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[NB * KV_BYTES + 4 * 16 * PPITCH];
@@ -67,18 +75,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   const int q0 = blockIdx.x * BQ;
   const int L = p.L;
 
-  // ---- Q fragments: lane (row l15 of this wave's 16, d = 32 ks + 8 g .. +7), scaled, bf16
+  // ---- Q fragments: lane (row l15 of this wave's 16, d = 32 ks + 8 g .. +7) as bf16; `scale` is applied to S in fp32
   uint4 qf[KS];
   {
     const int qi = q0 + wid * 16 + l15;
-    const float* qp = p.q + b * p.q_sb + h * p.q_sh + (int64_t)(qi < L ? qi : L - 1) * p.q_sl;
+    const IO* qp = reinterpret_cast<const IO*>(p.q) + b * p.q_sb + h * p.q_sh + (int64_t)(qi < L ? qi : L - 1) * p.q_sl;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float4 a = *reinterpret_cast<const float4*>(qp + 32 * ks + 8 * g);
-      const float4 c = *reinterpret_cast<const float4*>(qp + 32 * ks + 8 * g + 4);
-      qf[ks] = make_uint4(pack_bf16(a.x * p.scale, a.y * p.scale), pack_bf16(a.z * p.scale, a.w * p.scale),
-                          pack_bf16(c.x * p.scale, c.y * p.scale), pack_bf16(c.z * p.scale, c.w * p.scale));
-    }
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = load8_bf16(qp + 32 * ks + 8 * g);
   }
   // rows this lane owns in the accumulator layout: query 4 g + r of the wave's 16
   float m_run[4], l_run[4];
@@ -88,24 +91,24 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
 #pragma unroll
   for (int i = 0; i < DN; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const float* kbase = p.k + b * p.k_sb + h * p.k_sh;
-  const float* vbase = p.v + b * p.v_sb + h * p.v_sh;
+  const IO* kbase = reinterpret_cast<const IO*>(p.k) + b * p.k_sb + h * p.k_sh;
+  const IO* vbase = reinterpret_cast<const IO*>(p.v) + b * p.v_sb + h * p.v_sh;
   const int nt_all = (L + BK - 1) / BK;
   // causal: key tiles beyond this workgroup's last query row contribute nothing
   const int nt = p.causal ? min(nt_all, (min(q0 + BQ, L) + BK - 1) / BK) : nt_all;
 
-  float4 kr[CPT], vr[CPT];
+  uint4 kr[CPT], vr[CPT];       // the next tile, already bf16 (fp32 tensors are converted on arrival)
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tid + 256 * i, key = c / (D / 4), dc = c - key * (D / 4);
+      const int c = tid + 256 * i, key = c / (D / 8), dc = c - key * (D / 8);
       const int kj = t * BK + key;
       if (kj < L) {
-        kr[i] = *reinterpret_cast<const float4*>(kbase + (int64_t)kj * p.k_sl + dc * 4);
-        vr[i] = *reinterpret_cast<const float4*>(vbase + (int64_t)kj * p.v_sl + dc * 4);
+        kr[i] = load8_bf16(kbase + (int64_t)kj * p.k_sl + dc * 8);
+        vr[i] = load8_bf16(vbase + (int64_t)kj * p.v_sl + dc * 8);
       } else {
-        kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        kr[i] = make_uint4(0u, 0u, 0u, 0u);
+        vr[i] = make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
     unsigned char* Vd = Kd + BK * PITCH;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tid + 256 * i, key = c / (D / 4), dc = c - key * (D / 4);
-      *reinterpret_cast<uint2*>(Kd + key * PITCH + dc * 8) = make_uint2(pack_bf16(kr[i].x, kr[i].y), pack_bf16(kr[i].z, kr[i].w));
-      *reinterpret_cast<uint2*>(Vd + key * PITCH + dc * 8) = make_uint2(pack_bf16(vr[i].x, vr[i].y), pack_bf16(vr[i].z, vr[i].w));
+      const int c = tid + 256 * i, key = c / (D / 8), dc = c - key * (D / 8);
+      *reinterpret_cast<uint4*>(Kd + key * PITCH + dc * 16) = kr[i];
+      *reinterpret_cast<uint4*>(Vd + key * PITCH + dc * 16) = vr[i];
     }
   };
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int qi = q_lane0 + r;
         const bool valid = kj < L && qi < L && !(p.causal && kj > qi);
-        const float x = s[n][r] + madd[n] + badd[n][r];
+        const float x = s[n][r] * p.scale + madd[n] + badd[n][r];
         s[n][r] = x;
         ok[n][r] = valid;
         if (valid) mx[r] = fmaxf(mx[r], x);
@@ -240,30 +243,42 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   }
 
   // ---- O / l, LSE
-  float* obase = p.o + b * p.o_sb + h * p.o_sh;
+  IO* obase = reinterpret_cast<IO*>(p.o) + b * p.o_sb + h * p.o_sh;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int qi = q_lane0 + r;
     if (qi >= L) continue;
     const float inv = l_run[r] > 0.f ? 1.f / l_run[r] : 0.f;
 #pragma unroll
-    for (int dn = 0; dn < DN; ++dn) obase[(int64_t)qi * p.o_sl + 16 * dn + l15] = oacc[dn][r] * inv;
+    for (int dn = 0; dn < DN; ++dn) obase[(int64_t)qi * p.o_sl + 16 * dn + l15] = from_f32<IO>(oacc[dn][r] * inv);
     if (p.lse && l15 == 0) p.lse[(int64_t)bh * L + qi] = m_run[r] + __logf(fmaxf(l_run[r], 1e-38f));
   }
 }
 
 }  // namespace
 
+template <typename IO>
+static int flash_launch(FlashArgs& a, int Dh, hipStream_t st) {
+  const dim3 grid(ceil_div(a.L, 64), a.B * a.H);
+  static const int nb = [] { const char* e = getenv("MMSKIN_FLASH_BUFFERS"); return e ? atoi(e) : 2; }();
+  if (Dh == 32) { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<32, 1, IO>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<32, 2, IO>), grid, dim3(256), 0, st, a); }
+  else { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<64, 1, IO>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<64, 2, IO>), grid, dim3(256), 0, st, a); }
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 extern "C" {
 
-int mmskin_flash_attention_forward(const float* q, const float* k, const float* v, const float* mask_add, const float* bias,
-                                   float* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, float scale,
-                                   int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, const float* mask_add, const float* bias,
+                                   void* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, int io_dtype,
+                                   float scale, int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream) {
   ARG_CHECK(q && k && v && o && strides12, "flash_attention_forward: null argument");
   ARG_CHECK(B > 0 && H > 0 && L > 0 && (Dh == 32 || Dh == 64), "flash_attention_forward: B=%d H=%d L=%d Dh=%d (Dh must be 32 or 64)", B, H, L, Dh);
+  ARG_CHECK(io_dtype == MMSKIN_F32 || io_dtype == MMSKIN_BF16, "flash_attention_forward: io_dtype %d", io_dtype);
   ARG_CHECK(drop_p >= 0.f && drop_p < 1.f, "flash_attention_forward: dropout %f", drop_p);
   ARG_CHECK((int64_t)B * H <= 65535, "flash_attention_forward: B*H = %lld exceeds the grid", (long long)B * H);
-  for (int i = 0; i < 12; ++i) ARG_CHECK(strides12[i] % 4 == 0, "flash_attention_forward: stride %d = %lld is not a multiple of 4 elements (16-byte loads)", i, (long long)strides12[i]);
+  const int per16 = io_dtype == MMSKIN_BF16 ? 8 : 4;    // elements per 16-byte load
+  for (int i = 0; i < 9; ++i) ARG_CHECK(strides12[i] % per16 == 0, "flash_attention_forward: stride %d = %lld is not a multiple of %d elements (16-byte loads)", i, (long long)strides12[i], per16);
   ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "flash_attention_forward: q / k / v must be 16-byte aligned");
   FlashArgs a;
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.mask_add = mask_add; a.bias = bias;
@@ -273,13 +288,7 @@ int mmskin_flash_attention_forward(const float* q, const float* k, const float* 
   a.v_sb = strides12[6]; a.v_sh = strides12[7]; a.v_sl = strides12[8];
   a.o_sb = strides12[9]; a.o_sh = strides12[10]; a.o_sl = strides12[11];
   a.scale = scale; a.drop_p = drop_p; a.causal = causal; a.seed = seed; a.offset = offset;
-  const dim3 grid(ceil_div(L, 64), B * H);
-  hipStream_t st = (hipStream_t)stream;
-  static const int nb = [] { const char* e = getenv("MMSKIN_FLASH_BUFFERS"); return e ? atoi(e) : 2; }();
-  if (Dh == 32) { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<32, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<32, 2>), grid, dim3(256), 0, st, a); }
-  else { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<64, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<64, 2>), grid, dim3(256), 0, st, a); }
-  HIP_CHECK_RET(hipGetLastError());
-  return MMSKIN_OK;
+  return io_dtype == MMSKIN_BF16 ? flash_launch<bf16_t>(a, Dh, (hipStream_t)stream) : flash_launch<float>(a, Dh, (hipStream_t)stream);
 }
 
 }  // extern "C"

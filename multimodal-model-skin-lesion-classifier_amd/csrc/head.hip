@@ -295,6 +295,44 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// Inference-lane LayerNorm: one wave per row, the row held in registers (N <= 2048, N % 4 == 0: float4 loads, one pass over memory),
+// result written as fp32 and / or bf16 -- the bf16 copy is what the next Linear consumes in bf16-operand mode, so no separate
+// conversion pass runs.  No mean / rstd output: the lane is only taken when no gradient flows.
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                const float* __restrict__ b, float* __restrict__ y32,
+                                                                bf16_t* __restrict__ y16, int M, int N, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * N;
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = (j * 64 + lane) * 4;
+    v[j] = i < N ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mu = wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = (j * 64 + lane) * 4;
+    if (i < N) { const float a = v[j].x - mu, c = v[j].y - mu, d = v[j].z - mu, e = v[j].w - mu; q += (a * a + c * c) + (d * d + e * e); }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = (j * 64 + lane) * 4;
+    if (i >= N) continue;
+    const float4 gg = *reinterpret_cast<const float4*>(g + i), bb = *reinterpret_cast<const float4*>(b + i);
+    const float4 o = make_float4((v[j].x - mu) * rs * gg.x + bb.x, (v[j].y - mu) * rs * gg.y + bb.y,
+                                 (v[j].z - mu) * rs * gg.z + bb.z, (v[j].w - mu) * rs * gg.w + bb.w);
+    if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * N + i) = o;
+    if (y16) *reinterpret_cast<uint2*>(y16 + (int64_t)row * N + i) = make_uint2(f32_to_bf16_bits(o.x) | (f32_to_bf16_bits(o.y) << 16),
+                                                                                f32_to_bf16_bits(o.z) | (f32_to_bf16_bits(o.w) << 16));
+  }
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ g, const float* __restrict__ b,
                                                                const float* __restrict__ mean,
@@ -829,6 +867,50 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
   return MMSKIN_OK;
 }
 
+// Linear with bf16 tensors at either end (the inference lane of the transformer encoders in bf16-operand mode): x and / or y may be
+// bf16, so consecutive layers hand activations over without fp32 <-> bf16 conversion passes.  Shapes off the large-GEMM path (or
+// fp32 operand mode) fall back to the fp32 entry point through scratch conversions.
+int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, int M, int K, int N,
+                             int act, void* stream) {
+  ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward_ex: bad argument");
+  ARG_CHECK((x_dtype == 0 || x_dtype == 1) && (y_dtype == 0 || y_dtype == 1) && act >= 0 && act <= 2, "linear_forward_ex: dtype / activation");
+  hipStream_t st = ST(stream);
+  int rc;
+  if (linear_big(M, K, N) && linear_bf16()) {
+    ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+    const size_t xb = x_dtype == 1 ? 0 : align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb));
+    if (!sc) { mmskin_set_error("linear_forward_ex: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(x);
+    if (x_dtype == 0) {
+      if ((rc = cvt_to_bf16(reinterpret_cast<const float*>(x), reinterpret_cast<bf16_t*>(sc), (int64_t)M * K, st))) return rc;
+      x16 = reinterpret_cast<const bf16_t*>(sc);
+    }
+    bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb);
+    if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, st))) return rc;
+    FwdFuse f; f.bias = b; f.relu = act == 1; f.gelu = act == 2;
+    if (y_dtype == 0) f.out_f32 = reinterpret_cast<float*>(y);
+    return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, st, (b || act || y_dtype == 0) ? &f : nullptr);
+  }
+  const size_t xb = x_dtype == 1 ? align_up((size_t)M * K * 4, 256) : 0, yb = y_dtype == 1 ? align_up((size_t)M * N * 4, 256) : 0;
+  // (the fp32 entry point may itself use head_scratch: keep these conversions in a region of their own behind it)
+  static float* side = nullptr; static size_t side_bytes = 0;
+  if (xb + yb > side_bytes) {
+    if (side) HIP_CHECK_RET(hipFree(side));
+    HIP_CHECK_RET(hipMalloc((void**)&side, xb + yb));
+    side_bytes = xb + yb;
+  }
+  const float* xf = reinterpret_cast<const float*>(x);
+  if (x_dtype == 1) {
+    if ((rc = cvt_to_f32(reinterpret_cast<const bf16_t*>(x), side, (int64_t)M * K, st))) return rc;
+    xf = side;
+  }
+  float* yf = y_dtype == 1 ? reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(side) + xb) : reinterpret_cast<float*>(y);
+  if ((rc = mmskin_linear_forward(xf, w, b, yf, M, K, N, act, stream))) return rc;
+  if (y_dtype == 1) return cvt_to_bf16(yf, reinterpret_cast<bf16_t*>(y), (int64_t)M * N, st);
+  return MMSKIN_OK;
+}
+
 int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
                            float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
   ARG_CHECK(dy && M > 0 && K > 0 && N > 0, "linear_backward: bad argument");
@@ -900,6 +982,15 @@ int mmskin_layernorm_forward(const float* x, const float* g, const float* b, flo
                              int M, int N, float eps, int relu, void* stream) {
   ARG_CHECK(x && g && b && y && mean && rstd && M > 0 && N > 0, "layernorm_forward: bad argument");
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y, mean, rstd, M, N, eps, relu);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+int mmskin_layernorm_forward_mixed(const float* x, const float* g, const float* b, float* y_f32, void* y_bf16, int M, int N,
+                                   float eps, void* stream) {
+  ARG_CHECK(x && g && b && (y_f32 || y_bf16) && M > 0 && N > 0, "layernorm_forward_mixed: bad argument");
+  ARG_CHECK(N % 4 == 0 && N <= 2048, "layernorm_forward_mixed: N=%d (needs N %% 4 == 0 and N <= 2048)", N);
+  hipLaunchKernelGGL(layernorm_fwd_vec_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y_f32,
+                     reinterpret_cast<bf16_t*>(y_bf16), M, N, eps);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -60,7 +60,38 @@ class LinearFn(torch.autograd.Function):
         return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None
 
 
-def linear(x, w, b=None, relu=False):
+def lane_dtype(x, module=None, *tensors):
+    """torch.bfloat16 when the INFERENCE LANE applies to a layer -- bf16-operand mode and no gradient flows through it (input,
+    the module's parameters and `tensors` all without grad, or grad mode off): activations are then handed between the layer's
+    Linear / LayerNorm / attention ops as bf16 tensors, without fp32 <-> bf16 conversion passes.  None otherwise: the layer runs
+    its ordinary (differentiable, fp32-boundary) ops."""
+    if not x.is_cuda or get_linear_dtype() != "bf16":
+        return None
+    params = tuple(module.parameters()) if module is not None else ()
+    return None if _needs_grad(x, *params, *tensors) else torch.bfloat16
+
+
+def _linear_ex(x, w, b, act, out_dtype):
+    """no-grad Linear with bf16 and / or fp32 tensors at the boundary (mmskin_linear_forward_ex)."""
+    _need_gpu(x, "linear")
+    if _needs_grad(x, w, b):
+        raise _lib.MMSkinError("mmskin.linear: bf16 activations are an inference-lane feature (no gradient may flow through them)")
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    if x2.dtype not in (torch.float32, torch.bfloat16):
+        x2 = x2.float()
+    w = _f32c(w)
+    M, K = x2.shape
+    N = w.shape[0]
+    od = out_dtype or torch.float32
+    y = torch.empty((M, N), device=x.device, dtype=od)
+    call("mmskin_linear_forward_ex", ptr(x2), _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32, ptr(w), ptr(b), ptr(y),
+         _lib.BF16 if od == torch.bfloat16 else _lib.F32, M, K, N, int(act), stream())
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear(x, w, b=None, relu=False, out_dtype=None):
+    if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
+        return _linear_ex(x, w, b, 1 if relu else 0, out_dtype)
     return LinearFn.apply(x, w, b, relu)
 
 
@@ -97,8 +128,19 @@ class LayerNormFn(torch.autograd.Function):
         return (dx.reshape(ctx.xshape) if dx is not None else None), dg, db, None, None
 
 
-def layernorm(x, g, b, eps=1e-5, relu=False):
-    return LayerNormFn.apply(x, g, b, eps, relu)
+def layernorm(x, g, b, eps=1e-5, relu=False, out_dtype=None, keep_f32=False):
+    """nn.LayerNorm.  out_dtype=torch.bfloat16 (inference lane): the result as a bf16 tensor -- and with keep_f32 also the fp32
+    one (post-LN residual streams), returned as (fp32, bf16) -- from one pass over the row."""
+    N = x.shape[-1]
+    if out_dtype == torch.bfloat16 and not relu and N % 4 == 0 and N <= 2048 and not _needs_grad(x, g, b):
+        _need_gpu(x, "layernorm")
+        x2 = _f32c(x).reshape(-1, N)
+        y16 = torch.empty(x2.shape, device=x.device, dtype=torch.bfloat16)
+        y32 = torch.empty_like(x2) if keep_f32 else None
+        call("mmskin_layernorm_forward_mixed", ptr(x2), ptr(_f32c(g)), ptr(_f32c(b)), ptr(y32), ptr(y16), x2.shape[0], N, float(eps), stream())
+        return (y32.reshape(x.shape), y16.reshape(x.shape)) if keep_f32 else y16.reshape(x.shape)
+    y = LayerNormFn.apply(x, g, b, eps, relu)
+    return (y, y) if keep_f32 else y
 
 
 @no_second_order
@@ -341,6 +383,7 @@ def _flash_ok(q, k, v, mask_add, bias):
     through the attention (frozen encoders -- the reference's default `frozen_weights` -- and inference); trainable blocks
     keep the unfused path, which saves the probabilities for its backward."""
     return (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64) and q.is_cuda and q.shape == k.shape == v.shape
+            and q.dtype == k.dtype == v.dtype and q.dtype in (torch.float32, torch.bfloat16)
             and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v)))
 
 
@@ -350,8 +393,8 @@ def _flash_forward(q, k, v, out, dims, strides, mask_add, bias, causal, p, seed,
     m = _f32c(mask_add) if mask_add is not None else None
     bs = _f32c(bias) if bias is not None else None
     call("mmskin_flash_attention_forward", ptr(q), ptr(k), ptr(v), ptr(m) if m is not None else None,
-         ptr(bs) if bs is not None else None, ptr(out), None, B, H, L, Dh, st, 1.0 / Dh ** 0.5, int(causal), float(p),
-         int(seed), int(offset), stream())
+         ptr(bs) if bs is not None else None, ptr(out), None, B, H, L, Dh, st,
+         _lib.BF16 if q.dtype == torch.bfloat16 else _lib.F32, 1.0 / Dh ** 0.5, int(causal), float(p), int(seed), int(offset), stream())
     return out
 
 
@@ -368,14 +411,17 @@ def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=N
     is ONE fused kernel reading the qkv tensor in place; otherwise the views are permuted into the [B, H, L, Dh] ops."""
     B, L, H, Dh = q.shape
     p = dropout_p if training else 0.0
-    if _flash_ok(q, k, v, mask_add, bias) and all(t.dtype == torch.float32 and t.data_ptr() % 16 == 0 and
-                                                   all(s % 4 == 0 for s in t.stride()[:3]) for t in (q, k, v)):
+    per16 = 16 // q.element_size()
+    if _flash_ok(q, k, v, mask_add, bias) and all(t.data_ptr() % 16 == 0 and all(s % per16 == 0 for s in t.stride()[:3])
+                                                   for t in (q, k, v)):
         seed, offset = _dropout_state(p, B * H * L * L)
-        out = torch.empty((B, L, H, Dh), device=q.device, dtype=torch.float32)
+        out = torch.empty((B, L, H, Dh), device=q.device, dtype=q.dtype)
         strides = []
         for t in (q, k, v, out):
             strides += [t.stride(0), t.stride(2), t.stride(1)]        # (batch, head, token)
         return _flash_forward(q, k, v, out, (B, H, L, Dh), strides, mask_add, bias, causal, p, seed, offset)
+    if q.dtype == torch.bfloat16:     # bf16 views only exist on the inference lane; off the fused kernel's shapes go through fp32
+        q, k, v = q.float(), k.float(), v.float()
     o = attention(q.permute(0, 2, 1, 3).contiguous(), k.permute(0, 2, 1, 3).contiguous(), v.permute(0, 2, 1, 3).contiguous(),
                   dropout_p, training, mask_add, bias, causal)
     return o.permute(0, 2, 1, 3).contiguous()
@@ -385,7 +431,7 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, 
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
     if _flash_ok(q, k, v, mask_add, bias):
-        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         seed, offset = _dropout_state(p, B * H * L * L)
         out = torch.empty_like(q)
         strides = []
@@ -610,12 +656,14 @@ class GeluFn(torch.autograd.Function):
 gelu = GeluFn.apply
 
 
-def linear_gelu(x, w, b=None):
+def linear_gelu(x, w, b=None, out_dtype=None):
     """gelu(x @ w.T + b) -- the first half of a transformer MLP.  Without gradients (frozen encoders, inference) bias and the
     exact GELU run in the GEMM epilogue (one launch, the pre-activation never reaches memory); with gradients the two ops
     stay separate because GELU's backward needs the pre-activation."""
     if _needs_grad(x, w, b):
         return gelu(linear(x, w, b))
+    if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
+        return _linear_ex(x, w, b, 2, out_dtype)
     with torch.no_grad():
         return LinearFn.apply(x, w, b, 2)
 

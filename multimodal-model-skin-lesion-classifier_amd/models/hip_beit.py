@@ -63,11 +63,11 @@ class _Attention(nn.Module):
         self.register_buffer("k_bias", torch.zeros(dim), persistent=False)
         self.register_buffer("relative_position_index", relative_position_index(ws), persistent=False)
 
-    def forward(self, x, B, L):
+    def forward(self, x, B, L, od=None):
         H = self.num_heads
         E = x.shape[1]
         bias = torch.cat([self.q_bias, self.k_bias, self.v_bias])
-        qkv = ops.linear(x, self.qkv.weight, bias).reshape(B, L, 3, H, E // H)
+        qkv = ops.linear(x, self.qkv.weight, bias, out_dtype=od).reshape(B, L, 3, H, E // H)
         rel = self.relative_position_bias_table[self.relative_position_index.reshape(-1)].reshape(L, L, H).permute(2, 0, 1).contiguous()
         o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=rel)      # token-major views of the fused qkv output
         return self.proj(o.reshape(B * L, E))
@@ -80,8 +80,8 @@ class _Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = HipLinear(hidden, dim)
 
-    def forward(self, x):
-        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias))
+    def forward(self, x, od=None):
+        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias, out_dtype=od))
 
 
 class _Block(nn.Module):
@@ -95,8 +95,11 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, dim * 4)
 
     def forward(self, x, B, L):
-        x = ops.scale_add(x, self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, L), self.gamma_1)
-        return ops.scale_add(x, self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)), self.gamma_2)
+        od = ops.lane_dtype(x, self)     # bf16 activations between the ops of a block through which no gradient flows
+        a = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=od), B, L, od)
+        x = ops.scale_add(x, a, self.gamma_1)
+        m = self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=od), od)
+        return ops.scale_add(x, m, self.gamma_2)
 
 
 class HipBeit(nn.Module):

@@ -62,12 +62,11 @@ class _SelfAttention(nn.Module):
         self.value = HipLinear(c.hidden_size, c.hidden_size)
         self.dropout = HipDropout(c.attention_probs_dropout_prob)                  # applied inside ops.attention
 
-    def forward(self, x, B, L, mask_add):
+    def forward(self, x, B, L, mask_add, od=None):
         H = self.num_attention_heads
         E = x.shape[1]
-        split = lambda t: t.reshape(B, L, H, E // H)                                   # token-major: no permute copies
-        o = ops.attention_blhd(split(self.query(x)), split(self.key(x)), split(self.value(x)), self.dropout.p, self.training,
-                               mask_add=mask_add)
+        proj = lambda lin: ops.linear(x, lin.weight, lin.bias, out_dtype=od).reshape(B, L, H, E // H)   # token-major: no permute copies
+        o = ops.attention_blhd(proj(self.query), proj(self.key), proj(self.value), self.dropout.p, self.training, mask_add=mask_add)
         return o.reshape(B * L, E)
 
 
@@ -78,9 +77,11 @@ class _SelfOutput(nn.Module):
         self.LayerNorm = _ln(c.hidden_size, c.layer_norm_eps)
         self.dropout = HipDropout(c.hidden_dropout_prob)
 
-    def forward(self, h, residual):
+    def forward(self, h, residual, od=None):
+        """-> (fp32, bf16-or-same): the fp32 result is the residual stream, the second what the next Linear reads on the lane"""
         h = self.dropout(self.dense(h))
-        return ops.layernorm(ops.add(h, residual), self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        return ops.layernorm(ops.add(h, residual), self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
+                             out_dtype=od, keep_f32=True)
 
 
 class _Attention(nn.Module):
@@ -103,9 +104,13 @@ class _Layer(nn.Module):
         self.intermediate = _Intermediate(c)
         self.output = _SelfOutput(c, c.intermediate_size)
 
-    def forward(self, x, B, L, mask_add):
-        a = self.attention.output(self.attention.self(x, B, L, mask_add), x)
-        return self.output(ops.linear_gelu(a, self.intermediate.dense.weight, self.intermediate.dense.bias), a)
+    def forward(self, x, B, L, mask_add, x_lane=None):
+        """x: fp32 hidden states; x_lane: their bf16 copy when the previous layer ran on the inference lane.  -> (fp32, lane copy)"""
+        od = ops.lane_dtype(x, self)
+        xin = x_lane if (od is not None and x_lane is not None and x_lane.dtype == od) else x
+        a32, a_lane = self.attention.output(self.attention.self(xin, B, L, mask_add, od), x, od)
+        m = ops.linear_gelu(a_lane, self.intermediate.dense.weight, self.intermediate.dense.bias, out_dtype=od)
+        return self.output(m, a32, od)
 
 
 class _Encoder(nn.Module):
@@ -152,8 +157,9 @@ class HipBertModel(nn.Module):
         if attention_mask is not None:                                              # HF: (1 - mask) * finfo.min added to the scores
             mask_add = (1.0 - attention_mask.to(torch.float32)) * torch.finfo(torch.float32).min
         x = self.embeddings(input_ids, token_type_ids)
+        x_lane = None
         for layer in self.encoder.layer:
-            x = layer(x, B, L, mask_add)
+            x, x_lane = layer(x, B, L, mask_add, x_lane)
         hidden = x.reshape(B, L, -1)
         pooled = torch.tanh(self.pooler.dense(hidden[:, 0].contiguous()))           # unused by the reference
         return SimpleNamespace(last_hidden_state=hidden, pooler_output=pooled)

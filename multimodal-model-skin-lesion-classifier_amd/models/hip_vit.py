@@ -56,10 +56,10 @@ class _Attention(nn.Module):
         self.qkv = HipLinear(dim, dim * 3)
         self.proj = HipLinear(dim, dim)
 
-    def forward(self, x, B, L):
+    def forward(self, x, B, L, od=None):                # od = torch.bfloat16 on the inference lane (ops.lane_dtype), else None
         H = self.num_heads
         E = x.shape[1]
-        qkv = self.qkv(x).reshape(B, L, 3, H, E // H)                                           # token-major: read in place
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias, out_dtype=od).reshape(B, L, 3, H, E // H)   # token-major: read in place
         o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
         return self.proj(o.reshape(B * L, E))
 
@@ -71,8 +71,8 @@ class _Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = HipLinear(hidden, dim)
 
-    def forward(self, x):
-        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias))
+    def forward(self, x, od=None):
+        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias, out_dtype=od))
 
 
 class _Block(nn.Module):
@@ -84,8 +84,9 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, dim * 4)
 
     def forward(self, x, B, L):
-        x = ops.add(x, self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), B, L))
-        return ops.add(x, self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)))
+        od = ops.lane_dtype(x, self)     # bf16 activations between the ops of a block through which no gradient flows
+        x = ops.add(x, self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=od), B, L, od))
+        return ops.add(x, self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=od), od))
 
 
 class HipVisionTransformer(nn.Module):

@@ -152,3 +152,63 @@ def test_linear_gelu_epilogue(M, K, N):
     xr = x.clone().requires_grad_(True)
     torch.nn.functional.gelu(xr @ w.T + b).sum().backward()
     assert rel_err(xg.grad.cpu(), xr.grad) < 1e-3
+
+
+def test_flash_bf16_tensors_and_lane_ops():
+    """The inference lane's bf16 tensors: attention on bf16 q / k / v views (bf16 out), Linear with bf16 in / out and LayerNorm with a
+    bf16 (and fp32) result -- each against fp64 math on the values those tensors actually hold."""
+    ops.set_linear_dtype("bf16")
+    B, L, H, D = 2, 197, 4, 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, L, 3, H, D, generator=g).bfloat16()
+    want = _torch_ref(*(qkv[:, :, i].float().permute(0, 2, 1, 3) for i in range(3))).permute(0, 2, 1, 3)
+    qd = qkv.to(DEV)
+    with torch.no_grad():
+        got = ops.attention_blhd(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2])
+    assert got.dtype == torch.bfloat16 and got.shape == (B, L, H, D)
+    assert rel_err(got.float().cpu(), want) < 3e-2
+    # Linear: bf16 in -> bf16 out with GELU, bf16 in -> fp32 out, small shape through the fallback
+    for M, K, N in ((4096, 256, 512), (96, 64, 40)):
+        x = torch.randn(M, K, generator=g).bfloat16()
+        w, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+        ref = x.double() @ w.double().T + b.double()
+        with torch.no_grad():
+            y32 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV))
+            y16 = ops.linear_gelu(x.to(DEV), w.to(DEV), b.to(DEV), out_dtype=torch.bfloat16)
+        assert y32.dtype == torch.float32 and y16.dtype == torch.bfloat16
+        assert rel_err(y32.cpu(), ref.float()) < 2e-2
+        assert rel_err(y16.float().cpu(), torch.nn.functional.gelu(ref).float()) < 3e-2
+    # LayerNorm: one pass, fp32 + bf16 results
+    x = torch.randn(300, 768, generator=g)
+    gam, bet = torch.rand(768, generator=g) + 0.5, torch.randn(768, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (768,), gam.double(), bet.double(), 1e-6).float()
+    with torch.no_grad():
+        y32, y16 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-6, out_dtype=torch.bfloat16, keep_f32=True)
+    assert rel_err(y32.cpu(), ref) < 1e-5 and y16.dtype == torch.bfloat16 and rel_err(y16.float().cpu(), ref) < 1e-2
+    # a gradient-carrying input is refused on the lane instead of silently detached
+    with pytest.raises(Exception):
+        ops.linear(x.to(DEV).bfloat16().requires_grad_(True), w.to(DEV)[:, :768] if w.shape[1] >= 768 else torch.randn(8, 768, device=DEV))
+
+
+def test_bert_bf16_lane_matches_transformers():
+    """HipBertModel on the inference lane (bf16-operand mode, frozen: bf16 activations between Linear / LayerNorm / fused attention)
+    against transformers' BertModel in fp32 -- 512 tokens, padded rows."""
+    transformers = pytest.importorskip("transformers")
+    from models.hip_bert import HipBertModel
+    from oracle.detinit import det_init_
+    cfg = dict(vocab_size=200, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512, max_position_embeddings=512)
+    hf = det_init_(transformers.BertModel(transformers.BertConfig(**cfg))).eval()
+    hip = HipBertModel(**cfg)
+    hip.load_state_dict(hf.state_dict(), strict=True)
+    hip = hip.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 200, (6, 512), generator=g)
+    mask = torch.ones(6, 512, dtype=torch.long); mask[1, 300:] = 0; mask[4, 17:] = 0
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=mask).last_hidden_state[:, 0]
+        ops.set_linear_dtype("bf16")
+        got = hip(input_ids=ids.to(DEV), attention_mask=mask.to(DEV)).last_hidden_state[:, 0].cpu()
+        ops.set_linear_dtype("fp32")
+        exact = hip(input_ids=ids.to(DEV), attention_mask=mask.to(DEV)).last_hidden_state[:, 0].cpu()
+    assert rel_err(exact, want) < 5e-4
+    assert rel_err(got, want) < 5e-2, rel_err(got, want)
