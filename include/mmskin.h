@@ -219,6 +219,14 @@ int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, 
  * result written as fp32 (y_f32) and / or bf16 (y_bf16); N % 4 == 0, N <= 2048. */
 int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, int M, int K, int N,
                              int act, void* stream);
+/* linear_lane: the lane Linear with a frozen transformer block's elementwise tail fused into the GEMM epilogue,
+ *   y = residual + gamma * dropout(act(x w^T + b))     (residual fp32 [M][N], gamma fp32 [N], dropout: the generator of mmskin_dropout_forward
+ *   on element row * N + column; each optional).  w is fp32 or an already-converted bf16 copy (w_dtype).  Replaces the nn.Linear ->
+ *   nn.Dropout -> residual add chain of transformers' BertSelfOutput / BertOutput and timm's `x + gamma * proj(...)` (hip_bert.py, hip_beit.py).
+ *   Only for shapes on the large bf16 GEMM path (rows >= 2048, 64-multiple widths, bf16-operand mode): MMSKIN_ERR_ARG otherwise. */
+int mmskin_linear_lane(const void* x, int x_dtype, const void* w, int w_dtype, const float* b, const float* gamma,
+                       const float* residual, float drop_p, uint64_t seed, uint64_t offset, void* y, int y_dtype, int M, int K,
+                       int N, int act, void* stream);
 int mmskin_layernorm_forward_mixed(const float* x, const float* g, const float* b, float* y_f32, void* y_bf16, int M, int N,
                                    float eps, void* stream);
 /* Operand type of the large Linear GEMMs (rows >= 2048, 64-multiple widths: the transformer backbones' and BERT's

@@ -62,6 +62,25 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)f32_to_bf16_bits(v); }
 
 // One 16-byte chunk viewed as EPC floats.
+// splitmix64 finaliser: the counter-based generator of every dropout in the library (element i of a call = mix64(mix64(seed) ^ (offset + i)))
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// x * Phi(x) with Phi(-|x|) = erfc(|x| / sqrt 2) / 2 from Abramowitz & Stegun 7.1.26 (|error of erf| <= 1.5e-7, i.e. <= 0.75e-7 |x|
+// on the result: below bf16 AND below the fp32 rounding of an O(1) activation): 1 v_rcp + 1 v_exp + 9 multiply-adds, against the
+// ~40-instruction erff() whose cost in a GEMM epilogue was a quarter of the launch (fc1 of BEiT-large: 377 us -> see r02_experiments (10)).
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float tail = 0.5f * poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // Phi(-|x|)
+  return x * (x >= 0.f ? 1.f - tail : tail);
+}
+
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
   float v[4];

@@ -41,6 +41,11 @@ struct ConvGemmArgs {
   const float* ep_bias;    // inference: per-output-channel constant added to acc (+ addend) -- the folded BatchNorm shift
   int ep_relu;             // 1: ReLU on the stored value (folded-BN inference, Linear + ReLU); 2: exact GELU (transformer MLPs)
   float* out_f32;          // light-epilogue launches only: store the tile as fp32 HERE instead of T at `out` (Linear ops at the fp32 boundary)
+  // ---- transformer-residual epilogue (profile 6; Linear layers of frozen encoders): out_f32 = res_f32 + gamma * dropout(act(acc + bias))
+  const float* ep_gamma;   // optional per-output-channel multiplier (BEiT / DaViT layer scale)
+  const float* res_f32;    // optional fp32 residual stream, [rows][Cout]
+  float ep_drop_p;         // > 0: inverted dropout with the counter-based generator of the dropout op (element = row * Cout + column)
+  uint64_t ep_seed_mix, ep_offset;   // mix64(seed) and the call's counter offset
   const void* ep_x2;       // second raw tensor (downsample BN of the same block) -> stat_b_*
   float* stat_b_sum;       // = sum v   (again, so the downsample finalize sees the same slab layout)
   float* stat_b_sq;        // = sum v*ep_x2
@@ -77,6 +82,11 @@ struct FwdFuse {
   bool relu = false;
   bool gelu = false;              // exact GELU instead of ReLU
   float* out_f32 = nullptr;       // write the result as fp32 here (the T output pointer is then unused)
+  // transformer-residual epilogue: out = res_f32 + gamma * dropout(act(acc + bias))
+  const float* gamma = nullptr;   // [Cout]
+  const float* res_f32 = nullptr; // [rows][Cout] fp32
+  float drop_p = 0.f;
+  uint64_t seed = 0, offset = 0;
 };
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,

@@ -36,19 +36,20 @@ template <> struct Mma<float> {
   }
 };
 
-#define TAP_LDS_BYTES 2304   // tap table (3 x 16 ints) | output-row table of strided / multi-class launches (128 ints) | source-row table (3 x 128 ints)
+// LDS header: tap table (3 x 16 ints, 64 reserved) | output-row table of strided / multi-class launches (BM ints) | source-row table (3 x BM ints)
+template <int BM> constexpr int tap_lds_bytes() { return (64 + 4 * BM) * 4; }
 
 // 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
 __device__ uint4 g_zero_page[16];
 
-template <int BM, int BN, typename T, int NST> constexpr int conv_gemm_lds_bytes() {
+template <int BM, int BN, typename T, int NST, int NT = 256> constexpr int conv_gemm_lds_bytes() {
   constexpr int ab = NST * (BM + BN) * 128;
   constexpr int cpitch = BN * (int)sizeof(T) + 16;
-  constexpr int rows_per_pass = 256 / (BN / DT<T>::EPC);
+  constexpr int rows_per_pass = NT / (BN / DT<T>::EPC);
   constexpr int cs = BM * cpitch;                       // C staging; the stat reduction buffer overlays it
   constexpr int red = 3 * rows_per_pass * BN * 4;
   constexpr int m1 = ab > cs ? ab : cs;
-  return TAP_LDS_BYTES + (m1 > red ? m1 : red);
+  return tap_lds_bytes<BM>() + (m1 > red ? m1 : red);
 }
 
 // EPI = 0: plain epilogue (forward conv: store + BN partial sums); EPI = 1: addend and/or the fused
@@ -56,14 +57,20 @@ template <int BM, int BN, typename T, int NST> constexpr int conv_gemm_lds_bytes
 // NST = LDS stages: 2 = double-buffered K loop (2 workgroups per CU); 1 = single buffer, ~35 KB of LDS so
 // 3-4 workgroups share a CU -- for short-K, output-heavy layers where the epilogue dominates and only
 // inter-workgroup overlap can hide it.
+// WAVES_M x WAVES_N = 4 waves (256 threads, 128-row tiles, 2 - 4 workgroups per CU) or 8 waves (512 threads, the 256 x 256 tile: ONE
+// workgroup per CU with two waves per SIMD, half the L2 -> LDS fill bytes per FLOP of the 128 x 128 tile).
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int NST>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVES_N == 4) ? 4 : 2) void conv_gemm_kernel(const ConvGemmArgs p) {
   constexpr int EPC = DT<T>::EPC, BK = DT<T>::BK;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;     // threads
+  constexpr int PR = NT / 8;                     // tile rows one loader pass covers (8 chunks of 16 B per 128-byte row)
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
-  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int AP = BM / PR, BP = BN / PR;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int CPITCH = BN * (int)sizeof(T) + 16;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int TAP_LDS_BYTES = tap_lds_bytes<BM>();
+  static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
+  static_assert(BM <= NT && BN <= NT && BM % PR == 0 && BN % PR == 0, "tile / thread mismatch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* s_tap = reinterpret_cast<int*>(smem);
   unsigned char* As = smem + TAP_LDS_BYTES;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   // source pixel of every tile row: (image, y, x) costs two integer divisions -- one thread per ROW does them, not every
   // thread for each of its rows (eight threads share a row; the divisions were most of a short-K workgroup's prologue)
   const int ab = a_dim * b_dim;
-  int* s_src = s_tap + 192;   // [3][BM]: base offset, y, x
+  int* s_src = s_tap + 64 + BM;   // [3][BM]: base offset, y, x
   if (tid < BM) {
     const int m = m0 + tid;
     int base = 0, iy = -(1 << 20), ix = -(1 << 20);
@@ -110,13 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   int a_base[AP], a_iy[AP], a_ix[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int r = lr + 32 * i;
+    const int r = lr + PR * i;
     a_base[i] = s_src[r]; a_iy[i] = s_src[BM + r]; a_ix[i] = s_src[2 * BM + r];
   }
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
   const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w) +
                              (size_t)(n0 + lr) * p.wrow * sizeof(T);
-  const size_t w_pass = (size_t)32 * p.wrow * sizeof(T);
+  const size_t w_pass = (size_t)PR * p.wrow * sizeof(T);
 
   // LDS-DMA staging (global_load_lds_dwordx4): one wave-instruction lands 64 x 16 B = 8 tile rows
   // contiguously in LDS (wave-uniform base + lane*16), so the bank swizzle is applied to the per-lane
@@ -149,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                        \
       const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;            \
       const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);    \
-      GLDS16(ok ? src : zero_page, As + (buf) * A_BYTES + (32 * i + wid_u * 8) * 128);       \
+      GLDS16(ok ? src : zero_page, As + (buf) * A_BYTES + (PR * i + wid_u * 8) * 128);       \
     }                                                                                        \
     if (!(abl & 2)) _Pragma("unroll") for (int i = 0; i < BP; ++i)                           \
-      GLDS16(w_b + i * w_pass + (size_t)wk * sizeof(T), Bs + (buf) * B_BYTES + (32 * i + wid_u * 8) * 128); \
+      GLDS16(w_b + i * w_pass + (size_t)wk * sizeof(T), Bs + (buf) * B_BYTES + (PR * i + wid_u * 8) * 128); \
     c += BK;                                                                                 \
     const int wrap = (c >= C ? 1 : 0) + (c >= 2 * C ? 1 : 0);                                \
     c -= wrap * C;                                                                           \
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   __syncthreads();
 
   constexpr int CH_PER_ROW = BN / EPC;
-  constexpr int ROWS_PER_PASS = 256 / CH_PER_ROW;
+  constexpr int ROWS_PER_PASS = NT / CH_PER_ROW;
   const int cj = tid % CH_PER_ROW, r0 = tid / CH_PER_ROW;
   float ssum[EPC], ssq[EPC], ssb[EPC];
 #pragma unroll
@@ -252,7 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   //   3 x (+ mask from x*scale+shift) and the BatchNorm-backward sums          (dgrads into a conv -> BN -> ReLU unit)
   //   4 addend + 1-bit ReLU mask + x and the sums                               (dgrads into a residual block output)
   //   5 = 4 + x2 and its sums                                                   (... whose block has a downsample BatchNorm too)
-  constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5, HAS_BR = EPI == 1 || EPI == 2, HAS_MY = EPI == 1;
+  //   6 = 2 + layer scale, dropout and an fp32 residual stream                  (Linear layers of the frozen transformer encoders)
+  constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5, HAS_BR = EPI == 1 || EPI == 2 || EPI == 6, HAS_MY = EPI == 1;
+  constexpr bool HAS_TR = EPI == 6;
   constexpr bool HAS_MB = EPI == 1 || EPI == 4 || EPI == 5, HAS_X = EPI == 1 || EPI >= 3, HAS_X2 = EPI == 1 || EPI == 5;
   const unsigned char* add_b = HAS_ADD ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
   const unsigned char* my_b = HAS_MY ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
@@ -269,6 +278,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) ebias[e] = p.ep_bias[n0 + cj * EPC + e];
   }
+  const float* res_f32 = HAS_TR ? p.res_f32 : nullptr;
+  const bool has_gamma = HAS_TR && p.ep_gamma != nullptr;
+  const float drop_p = HAS_TR ? p.ep_drop_p : 0.f;
+  const float drop_scale = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
+  float egam[EPC];
+  if (has_gamma) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) egam[e] = p.ep_gamma[n0 + cj * EPC + e];
+  }
   float esc[EPC], esh[EPC];
   if (mask_from_x) {
 #pragma unroll
@@ -278,11 +296,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
   // issued before any of them is consumed, so EG*3 16-byte loads are in flight per lane instead of one
   // dependent load->store chain per row (the fused epilogue was running at ~3 TB/s that way).
   constexpr int NR = BM / ROWS_PER_PASS;
-  constexpr int EG = NR < 4 ? NR : 4;
+  constexpr int EG_MAX = EPI == 6 ? 2 : 4;   // profile 6 holds 32 B of fp32 residual per row in flight: two rows keep it at the main loop's register count
+  constexpr int EG = NR < EG_MAX ? NR : EG_MAX;
   static_assert(NR % EG == 0, "row groups");
   const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
   for (int grp = 0; grp < NR; grp += EG) {
     u32x4_t q_ad[EG], q_my[EG], q_x[EG], q_x2[EG];
+    float4 q_res[EG][EPC / 4];
     uint32_t q_mb[EG];
     size_t goffs[EG];
     bool valid[EG];
@@ -302,6 +322,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
         q_x[k] = *reinterpret_cast<const u32x4_t*>(ex_b && valid[k] ? ex_b + xoff : zp);
       }
       if constexpr (HAS_X2) q_x2[k] = *reinterpret_cast<const u32x4_t*>(ex2_b && valid[k] ? ex2_b + goffs[k] : zp);
+      if constexpr (HAS_TR) {
+        if (res_f32 && valid[k]) {
+#pragma unroll
+          for (int e = 0; e < EPC / 4; ++e) q_res[k][e] = *reinterpret_cast<const float4*>(res_f32 + goffs[k] / sizeof(T) + 4 * e);
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < EG; ++k) {
@@ -325,7 +351,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
       }
       if (do_gelu) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v.v[e] = 0.5f * v.v[e] * (1.f + erff(v.v[e] * 0.70710678118654752f));
+        for (int e = 0; e < EPC; ++e) v.v[e] = gelu_erf_fast(v.v[e]);
+      }
+      if constexpr (HAS_TR) {
+        if (drop_p > 0.f) {
+          // keep bits first (one rolled loop: eight interleaved 64-bit hash chains cost a wave per SIMD in registers), then applied
+          const uint64_t gi = p.ep_offset + goffs[k] / sizeof(T);
+          uint32_t keep = 0;
+#pragma unroll 1
+          for (int e = 0; e < EPC; ++e) {
+            const uint64_t h = mix64(p.ep_seed_mix ^ (gi + (uint64_t)e));
+            keep |= ((float)(h >> 40) * (1.0f / 16777216.0f) >= drop_p ? 1u : 0u) << e;
+          }
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v.v[e] = ((keep >> e) & 1u) ? v.v[e] * drop_scale : 0.f;
+        }
+        if (has_gamma) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v.v[e] *= egam[e];
+        }
+        if (res_f32) {
+#pragma unroll
+          for (int e = 0; e < EPC / 4; ++e) {
+            v.v[4 * e] += q_res[k][e].x; v.v[4 * e + 1] += q_res[k][e].y; v.v[4 * e + 2] += q_res[k][e].z; v.v[4 * e + 3] += q_res[k][e].w;
+          }
+        }
       }
       if (my_b) {
         Chunk<T> my;
@@ -398,7 +448,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs p)
 // ------------------------------------------------------------------------------------------ host
 template <typename T, int BM, int BN, int WMv, int WNv, int EPI, int NST>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
-  constexpr int lds = conv_gemm_lds_bytes<BM, BN, T, NST>();
+  constexpr int NT = 64 * WMv * WNv;
+  constexpr int lds = conv_gemm_lds_bytes<BM, BN, T, NST, NT>();
   static bool attr_done = false;
   auto kern = conv_gemm_kernel<T, BM, BN, WMv, WNv, EPI, NST>;
   if (!attr_done) {
@@ -408,7 +459,7 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   }
   int grid = a.total_mblk * a.nblk_n;
   if (grid == 0) return MMSKIN_OK;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -426,7 +477,8 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
 #ifdef MMSKIN_ABLATE
   { const char* abl = getenv("MMSKIN_CONV_ABLATE"); a.ablate = abl ? atoi(abl) : 0; }
 #endif
-  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32;
+  const bool tr = a.ep_gamma || a.res_f32 || a.ep_drop_p > 0.f;   // transformer-residual epilogue
+  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32 || tr;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
@@ -434,6 +486,21 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   static const int nst1_min_blocks_epi = [] { const char* v = getenv("MMSKIN_CONV_NST1_MINBLOCKS_EPI"); return v ? atoi(v) : 800; }();   // fused-epilogue launches: 168 VGPRs = 3 workgroups/CU = 768 single-buffer slots; a 784-workgroup launch would spill into a second round
   const int bn_sel = (a.Cout % 128 == 0) ? 128 : 64;
   const bool heavy = a.ep_mask_y || a.ep_mask_bits || a.ep_x;   // needs a fused BatchNorm-backward epilogue
+  // 256 x 256 tile, 8 waves (one workgroup per CU, half the L2 -> LDS bytes per FLOP): plain GEMM-like launches (one tap class, no
+  // statistics, light epilogue) with a deep reduction whose grid still covers the chip -- fc2 / output.dense of the transformer
+  // encoders (K = 3072 / 4096: 1.03 - 1.05 PFLOP/s against 0.88 - 0.92 on the 128 x 128 tile; at K <= 1024 the per-tile prologue and
+  // the 2-wave-per-SIMD epilogue cost more than the fill saves: profiles/r02_experiments.txt (9)).  MMSKIN_GEMM_BIG_MINK=0: off.
+  static const int big_min_k = [] { const char* v = getenv("MMSKIN_GEMM_BIG_MINK"); return v ? atoi(v) : 2048; }();
+  if constexpr (sizeof(T) == 2) {
+    if (big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
+        a.cls[0].mblk_start == 0 && a.cls[0].ntaps == 1 && a.Sy == 1 && a.Sx == 1 && a.OS == 1) {   // plain GEMMs only (what the tests cover)
+      const int mb = ceil_div(a.cls[0].rows, 256), nb = a.Cout / 256;
+      if (mb * nb >= 224) {
+        a.total_mblk = mb; a.nblk_n = nb;
+        return !epi ? launch_cfg<T, 256, 256, 2, 4, 0, 2>(a, st) : (tr ? launch_cfg<T, 256, 256, 2, 4, 6, 2>(a, st) : launch_cfg<T, 256, 256, 2, 4, 2, 2>(a, st));
+      }
+    }
+  }
   static const bool profiles_on = [] { const char* v = getenv("MMSKIN_CONV_EPI_PROFILES"); return !v || atoi(v) != 0; }();
   int prof = 1;
   if (profiles_on && heavy && !a.ep_mask_y && !a.ep_bias && !a.ep_relu) {
@@ -443,6 +510,12 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   // only the everything-profile is a 168-VGPR kernel (768 single-buffer slots); the others have the forward kernel's residency
   const bool one = a.total_mblk * (a.Cout / bn_sel) > ((heavy && prof == 1) ? nst1_min_blocks_epi : nst1_min_blocks);
 #define GO(BNv, E) (one ? launch_cfg<T, CONV_BM, BNv, 2, 2, E, 1>(a, st) : launch_cfg<T, CONV_BM, BNv, 2, 2, E, 2>(a, st))
+  if (tr) {
+    ARG_CHECK(!heavy && !a.addend && !a.stat_sum && a.out_f32 && a.Cout % 128 == 0,
+              "conv_gemm: the transformer-residual epilogue needs an fp32 output, Cout %% 128 == 0 and no other fused operand");
+    if constexpr (sizeof(T) == 2) { a.nblk_n = a.Cout / 128; return GO(128, 6); }
+    ARG_CHECK(false, "conv_gemm: the transformer-residual epilogue is a bf16-operand feature");
+  }
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
     return !epi ? GO(128, 0) : (!heavy ? GO(128, 2) : (prof == 3 ? GO(128, 3) : (prof == 4 ? GO(128, 4) : (prof == 5 ? GO(128, 5) : GO(128, 1)))));
@@ -471,7 +544,10 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
-  if (fuse) { a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->gelu ? 2 : (fuse->relu ? 1 : 0); a.out_f32 = fuse->out_f32; }
+  if (fuse) {
+    a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->gelu ? 2 : (fuse->relu ? 1 : 0); a.out_f32 = fuse->out_f32;
+    a.ep_gamma = fuse->gamma; a.res_f32 = fuse->res_f32; a.ep_drop_p = fuse->drop_p; a.ep_seed_mix = mix64(fuse->seed); a.ep_offset = fuse->offset;
+  }
   a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
   a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;

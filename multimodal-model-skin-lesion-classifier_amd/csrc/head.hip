@@ -457,12 +457,6 @@ __global__ void metablock_gate_bwd_kernel(const float* dout, const float* V, con
   }
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __global__ void dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
                                    uint64_t offset) {
   const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
@@ -909,6 +903,44 @@ int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const f
   if ((rc = mmskin_linear_forward(xf, w, b, yf, M, K, N, act, stream))) return rc;
   if (y_dtype == 1) return cvt_to_bf16(yf, reinterpret_cast<bf16_t*>(y), (int64_t)M * N, st);
   return MMSKIN_OK;
+}
+
+// The lane Linear with everything a frozen transformer block hangs on its GEMMs fused into the epilogue:
+//   y = residual + gamma * dropout(act(x w^T + b))          (each of residual / gamma / dropout optional)
+// x fp32 or bf16; w fp32 (converted per call) or bf16 (a cached conversion of a frozen weight: no per-step conversion pass);
+// residual fp32 [M][N]; with any of the three, y must be fp32 (the residual stream).  bf16-operand mode and the large-GEMM shape
+// class only: the op has no fp32 formulation (the caller composes the separate ops instead).
+int mmskin_linear_lane(const void* x, int x_dtype, const void* w, int w_dtype, const float* b, const float* gamma,
+                       const float* residual, float drop_p, uint64_t seed, uint64_t offset, void* y, int y_dtype, int M, int K,
+                       int N, int act, void* stream) {
+  ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_lane: bad argument");
+  ARG_CHECK((x_dtype == 0 || x_dtype == 1) && (w_dtype == 0 || w_dtype == 1) && (y_dtype == 0 || y_dtype == 1) && act >= 0 && act <= 2,
+            "linear_lane: dtype / activation");
+  ARG_CHECK(drop_p >= 0.f && drop_p < 1.f, "linear_lane: dropout probability %f", (double)drop_p);
+  ARG_CHECK(linear_big(M, K, N) && linear_bf16(), "linear_lane: M=%d K=%d N=%d is off the large bf16 GEMM path (rows >= 2048, 64-multiple widths, "
+            "MMSKIN_LINEAR_DTYPE=bf16)", M, K, N);
+  const bool tr = gamma || residual || drop_p > 0.f;
+  ARG_CHECK(!tr || (y_dtype == 0 && N % 128 == 0), "linear_lane: residual / layer scale / dropout need an fp32 result and N %% 128 == 0");
+  hipStream_t st = ST(stream);
+  int rc;
+  ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
+  const size_t xb = x_dtype == 1 ? 0 : align_up((size_t)M * K * 2, 256), wb = w_dtype == 1 ? 0 : align_up((size_t)N * K * 2, 256);
+  unsigned char* sc = (xb + wb) ? reinterpret_cast<unsigned char*>(head_scratch(xb + wb)) : nullptr;
+  if ((xb + wb) && !sc) { mmskin_set_error("linear_lane: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+  const bf16_t* x16 = reinterpret_cast<const bf16_t*>(x);
+  if (x_dtype == 0) {
+    if ((rc = cvt_to_bf16(reinterpret_cast<const float*>(x), reinterpret_cast<bf16_t*>(sc), (int64_t)M * K, st))) return rc;
+    x16 = reinterpret_cast<const bf16_t*>(sc);
+  }
+  const bf16_t* w16 = reinterpret_cast<const bf16_t*>(w);
+  if (w_dtype == 0) {
+    if ((rc = cvt_to_bf16(reinterpret_cast<const float*>(w), reinterpret_cast<bf16_t*>(sc + xb), (int64_t)N * K, st))) return rc;
+    w16 = reinterpret_cast<const bf16_t*>(sc + xb);
+  }
+  FwdFuse f; f.bias = b; f.relu = act == 1; f.gelu = act == 2;
+  if (y_dtype == 0) f.out_f32 = reinterpret_cast<float*>(y);
+  f.gamma = gamma; f.res_f32 = residual; f.drop_p = drop_p; f.seed = seed; f.offset = offset;
+  return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, st, (b || act || y_dtype == 0 || tr) ? &f : nullptr);
 }
 
 int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,

@@ -89,9 +89,72 @@ def _linear_ex(x, w, b, act, out_dtype):
     return y.reshape(*x.shape[:-1], N)
 
 
+_frozen_cache = {}   # (data_ptr, ...) -> (versions, weakrefs, bf16 tensor)
+
+
+def frozen_bf16(*ws):
+    """bf16 copy of one weight (or of several stacked along dim 0: the q / k / v projections of a BERT layer as ONE [3E, E] operand)
+    that no gradient flows into, converted once and reused until a source tensor changes (its version counter moves: optimizer
+    step, load_state_dict, .copy_) or is replaced.  Saves the per-step fp32 -> bf16 pass over every frozen encoder weight."""
+    import weakref
+    key = tuple(w.data_ptr() for w in ws)
+    vers = tuple(w._version for w in ws)
+    hit = _frozen_cache.get(key)
+    if hit is not None and hit[0] == vers and all(r() is w for r, w in zip(hit[1], ws)):
+        return hit[2]
+    with torch.no_grad():
+        w16 = (ws[0] if len(ws) == 1 else torch.cat([w.reshape(w.shape[0], -1) for w in ws], 0)).to(torch.bfloat16).contiguous()
+    if len(_frozen_cache) > 4096:
+        _frozen_cache.clear()
+    _frozen_cache[key] = (vers, tuple(weakref.ref(w) for w in ws), w16)
+    return w16
+
+
+def lane_ok(x, N, K, fused_tail=False):
+    """does mmskin_linear_lane take this shape?  (rows >= 2048, 64-multiple widths; 128-multiple N with a fused residual tail)"""
+    M = x.numel() // x.shape[-1]
+    return x.is_cuda and get_linear_dtype() == "bf16" and M >= 2048 and K % 64 == 0 and N % (128 if fused_tail else 64) == 0
+
+
+def linear_lane(x, ws, b=None, act=0, gamma=None, residual=None, drop_p=0.0, training=False, out_dtype=None):
+    """y = residual + gamma * dropout(act(x @ W.T + b)) as ONE GEMM launch on the inference lane (no gradient flows: frozen
+    encoders / evaluation; bf16-operand mode).  ws: a weight or a tuple of weights stacked along the output dimension; their
+    bf16 copy is cached (frozen_bf16).  act 0 none / 1 ReLU / 2 exact GELU.  With residual / gamma / dropout the result is the
+    fp32 residual stream; otherwise out_dtype (fp32 default).  Shapes the fused kernel does not take are composed from the
+    separate ops (same arithmetic, more launches)."""
+    ws = ws if isinstance(ws, (tuple, list)) else (ws,)
+    _need_gpu(x, "linear_lane")
+    if _needs_grad(x, *ws, b, gamma, residual):
+        raise _lib.MMSkinError("mmskin.linear_lane: an inference-lane op (no gradient may flow through it)")
+    p = float(drop_p) if training else 0.0
+    tail = gamma is not None or residual is not None or p > 0.0
+    K = x.shape[-1]
+    N = sum(w.shape[0] for w in ws)
+    if not lane_ok(x, N, K, tail):
+        w = ws[0] if len(ws) == 1 else torch.cat(list(ws), 0)
+        h = _linear_ex(x, w, b, act, None if tail else out_dtype)
+        if p > 0.0:
+            h = dropout(h, p, True)
+        if gamma is not None:
+            return scale_add(residual if residual is not None else torch.zeros_like(h), h, gamma)
+        return add(h, residual) if residual is not None else h
+    x2 = x.reshape(-1, K).contiguous()
+    if x2.dtype not in (torch.float32, torch.bfloat16):
+        x2 = x2.float()
+    M = x2.shape[0]
+    od = torch.float32 if tail else (out_dtype or torch.float32)
+    y = torch.empty((M, N), device=x.device, dtype=od)
+    res = None if residual is None else _f32c(residual).reshape(M, N)
+    seed, offset = _dropout_state(p, M * N)
+    call("mmskin_linear_lane", ptr(x2), _lib.BF16 if x2.dtype == torch.bfloat16 else _lib.F32, ptr(frozen_bf16(*ws)), _lib.BF16,
+         ptr(None if b is None else _f32c(b)), ptr(None if gamma is None else _f32c(gamma)), ptr(res), p, int(seed), int(offset),
+         ptr(y), _lib.BF16 if od == torch.bfloat16 else _lib.F32, M, K, N, int(act), stream())
+    return y.reshape(*x.shape[:-1], N)
+
+
 def linear(x, w, b=None, relu=False, out_dtype=None):
     if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
-        return _linear_ex(x, w, b, 1 if relu else 0, out_dtype)
+        return linear_lane(x, w, b, 1 if relu else 0, out_dtype=out_dtype)
     return LinearFn.apply(x, w, b, relu)
 
 
@@ -663,7 +726,7 @@ def linear_gelu(x, w, b=None, out_dtype=None):
     if _needs_grad(x, w, b):
         return gelu(linear(x, w, b))
     if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
-        return _linear_ex(x, w, b, 2, out_dtype)
+        return linear_lane(x, w, b, 2, out_dtype=out_dtype)
     with torch.no_grad():
         return LinearFn.apply(x, w, b, 2)
 

@@ -70,7 +70,7 @@ class _Attention(nn.Module):
         qkv = ops.linear(x, self.qkv.weight, bias, out_dtype=od).reshape(B, L, 3, H, E // H)
         rel = self.relative_position_bias_table[self.relative_position_index.reshape(-1)].reshape(L, L, H).permute(2, 0, 1).contiguous()
         o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=rel)      # token-major views of the fused qkv output
-        return self.proj(o.reshape(B * L, E))
+        return o.reshape(B * L, E)                                                      # the caller applies self.proj
 
 
 class _Mlp(nn.Module):
@@ -80,8 +80,11 @@ class _Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = HipLinear(hidden, dim)
 
+    def hidden(self, x, od=None):
+        return ops.linear_gelu(x, self.fc1.weight, self.fc1.bias, out_dtype=od)
+
     def forward(self, x, od=None):
-        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias, out_dtype=od))
+        return self.fc2(self.hidden(x, od))
 
 
 class _Block(nn.Module):
@@ -97,7 +100,12 @@ class _Block(nn.Module):
     def forward(self, x, B, L):
         od = ops.lane_dtype(x, self)     # bf16 activations between the ops of a block through which no gradient flows
         a = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, out_dtype=od), B, L, od)
-        x = ops.scale_add(x, a, self.gamma_1)
+        if od is not None:
+            # lane: bias, layer scale and the residual add of `x + gamma * proj(a)` / `x + gamma * fc2(h)` run in the GEMM epilogue
+            x = ops.linear_lane(a, self.attn.proj.weight, self.attn.proj.bias, gamma=self.gamma_1, residual=x)
+            h = self.mlp.hidden(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=od), od)
+            return ops.linear_lane(h, self.mlp.fc2.weight, self.mlp.fc2.bias, gamma=self.gamma_2, residual=x)
+        x = ops.scale_add(x, self.attn.proj(a), self.gamma_1)
         m = self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=od), od)
         return ops.scale_add(x, m, self.gamma_2)
 

@@ -65,6 +65,11 @@ class _SelfAttention(nn.Module):
     def forward(self, x, B, L, mask_add, od=None):
         H = self.num_attention_heads
         E = x.shape[1]
+        if od is not None:   # lane: the three projections as ONE GEMM over the stacked (cached bf16) weights
+            qkv = ops.linear_lane(x, (self.query.weight, self.key.weight, self.value.weight),
+                                  torch.cat([self.query.bias, self.key.bias, self.value.bias]), out_dtype=od).reshape(B, L, 3, H, E // H)
+            o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], self.dropout.p, self.training, mask_add=mask_add)
+            return o.reshape(B * L, E)
         proj = lambda lin: ops.linear(x, lin.weight, lin.bias, out_dtype=od).reshape(B, L, H, E // H)   # token-major: no permute copies
         o = ops.attention_blhd(proj(self.query), proj(self.key), proj(self.value), self.dropout.p, self.training, mask_add=mask_add)
         return o.reshape(B * L, E)
@@ -79,9 +84,11 @@ class _SelfOutput(nn.Module):
 
     def forward(self, h, residual, od=None):
         """-> (fp32, bf16-or-same): the fp32 result is the residual stream, the second what the next Linear reads on the lane"""
-        h = self.dropout(self.dense(h))
-        return ops.layernorm(ops.add(h, residual), self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
-                             out_dtype=od, keep_f32=True)
+        if od is not None:   # lane: bias, hidden dropout and the residual add run in the GEMM epilogue
+            h = ops.linear_lane(h, self.dense.weight, self.dense.bias, residual=residual, drop_p=self.dropout.p, training=self.training)
+        else:
+            h = ops.add(self.dropout(self.dense(h)), residual)
+        return ops.layernorm(h, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, out_dtype=od, keep_f32=True)
 
 
 class _Attention(nn.Module):

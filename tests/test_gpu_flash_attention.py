@@ -212,3 +212,51 @@ def test_bert_bf16_lane_matches_transformers():
         exact = hip(input_ids=ids.to(DEV), attention_mask=mask.to(DEV)).last_hidden_state[:, 0].cpu()
     assert rel_err(exact, want) < 5e-4
     assert rel_err(got, want) < 5e-2, rel_err(got, want)
+
+
+def test_linear_lane_fused_tail_matches_separate_ops():
+    """mmskin_linear_lane: y = residual + gamma * dropout(act(x W^T + b)) in the GEMM epilogue against the same chain of separate
+    ops (Linear on the lane -> dropout op -> scale_add): identical dropout mask (same generator, same element index), bf16-rounded
+    GEMM result in both, so the two agree to fp32 rounding; stacked weights = one GEMM over the concatenation; the cached bf16
+    weight follows in-place updates of its source; shapes off the fused path are composed from the separate ops."""
+    ops.set_linear_dtype("bf16")
+    g = torch.Generator().manual_seed(21)
+    M, K, N = 4096 + 40, 256, 384                       # ragged last row block
+    x = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b, gam = torch.randn(N, generator=g).to(DEV), (torch.rand(N, generator=g) + 0.5).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    with torch.no_grad():
+        for act, p, use_g, use_r in ((0, 0.0, True, True), (2, 0.0, False, True), (0, 0.1, False, True), (1, 0.25, True, True), (0, 0.1, False, False)):
+            state = list(ops._dropout_counter)
+            y = ops.linear_lane(x, w, b, act, gam if use_g else None, res if use_r else None, p, True)
+            ops._dropout_counter[:] = state               # replay the same dropout call for the separate ops
+            h = ops.linear_lane(x, w, b, act)                                  # fp32 out, plain epilogue
+            if p > 0:
+                h = ops.dropout(h, p, True)
+            want = h * (gam if use_g else 1.0) + (res if use_r else 0.0)
+            assert y.dtype == torch.float32 and y.shape == (M, N)
+            assert rel_err(y.cpu(), want.cpu()) < 1e-6, (act, p, use_g, use_r, rel_err(y.cpu(), want.cpu()))
+            if p > 0 and act == 0:
+                assert abs(float((h == 0).float().mean()) - p) < 0.01
+        # against fp64 math on the bf16 operands
+        ref = res.double().cpu() + gam.double().cpu() * (x.double().cpu() @ w.bfloat16().double().cpu().T + b.double().cpu())
+        assert rel_err(ops.linear_lane(x, w, b, 0, gam, res).cpu(), ref.float()) < 2e-2
+        # stacked weights: one GEMM over the concatenation
+        w2 = (torch.randn(128, K, generator=g) / K ** 0.5).to(DEV)
+        b2 = torch.randn(N + 128, generator=g).to(DEV)
+        ys = ops.linear_lane(x, (w, w2), b2, out_dtype=torch.bfloat16)
+        yc = ops.linear_lane(x, torch.cat([w, w2]), b2, out_dtype=torch.bfloat16)
+        assert ys.dtype == torch.bfloat16 and torch.equal(ys, yc)
+        # the cache follows an in-place update of the source weight
+        y0 = ops.linear_lane(x, w, b)
+        w.mul_(2.0)
+        y1 = ops.linear_lane(x, w, b)
+        assert rel_err((y1 - b).cpu(), (2.0 * (y0 - b)).cpu()) < 1e-2
+        # off the fused path (few rows; N not a multiple of 128 with a tail): composed from the separate ops
+        xs = torch.randn(96, 64, generator=g).to(DEV)
+        ws, rs = torch.randn(40, 64, generator=g).to(DEV), torch.randn(96, 40, generator=g).to(DEV)
+        ysm = ops.linear_lane(xs, ws, None, 0, None, rs)
+        assert rel_err(ysm.cpu(), (xs @ ws.T + rs).cpu()) < 2e-2
+    with pytest.raises(Exception):
+        ops.linear_lane(x.float().requires_grad_(True), w, b)
