@@ -219,6 +219,18 @@ int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, 
  * result written as fp32 (y_f32) and / or bf16 (y_bf16); N % 4 == 0, N <= 2048. */
 int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const float* b, void* y, int y_dtype, int M, int K, int N,
                              int act, void* stream);
+/* Small-sequence attention, one wave per (batch, head): L <= 64, Dh 32 or 64, fp32, softmax(q k^T * scale) v with optional dropout on the
+ * probabilities (generator of mmskin_dropout_forward on element ((b*H + h)*L + i)*L + j).  q / k / v -- and dq / dk / dv -- are addressed by
+ * the (batch, head, token) ELEMENT strides qkv_strides[3], o / dO by o_strides[3] (rows 16-byte aligned, Dh contiguous), so the packed
+ * [B, L, 3, H, Dh] output of a fused qkv Linear is read in place and o is written token-major.  lse [B*H][L] (row log-sum-exp) is all the
+ * backward needs besides q, k, v, o: no probability tensor is stored.  Replaces timm's window / global Attention.forward and
+ * nn.MultiheadAttention's core for those shapes with gradients (DaViT WindowAttention: 49 tokens, Dh 32; hip_davit.py). */
+int mmskin_attention_rows_forward(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L, int Dh,
+                                  const int64_t* qkv_strides, const int64_t* o_strides, float scale, float drop_p, uint64_t seed,
+                                  uint64_t offset, void* stream);
+int mmskin_attention_rows_backward(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
+                                   float* dq, float* dk, float* dv, int B, int H, int L, int Dh, const int64_t* qkv_strides,
+                                   const int64_t* o_strides, float scale, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 /* linear_lane: the lane Linear with a frozen transformer block's elementwise tail fused into the GEMM epilogue,
  *   y = residual + gamma * dropout(act(x w^T + b))     (residual fp32 [M][N], gamma fp32 [N], dropout: the generator of mmskin_dropout_forward
  *   on element row * N + column; each optional).  w is fp32 or an already-converted bf16 copy (w_dtype).  Replaces the nn.Linear ->

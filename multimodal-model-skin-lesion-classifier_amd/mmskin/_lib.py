@@ -101,6 +101,8 @@ _SIGNATURES = {
     "mmskin_direct_conv2d_forward": (_i, [_P] * 4 + [_i] * 10 + [_P]),
     "mmskin_direct_conv2d_backward": (_i, [_P] * 5 + [_i] * 9 + [_P]),
     "mmskin_linear_forward_ex": (_i, [_P, _i, _P, _P, _P, _i, _i, _i, _i, _i, _P]),
+    "mmskin_attention_rows_forward": (_i, [_P] * 5 + [_i] * 4 + [_P, _P, _f, _f, _u64, _u64, _P]),
+    "mmskin_attention_rows_backward": (_i, [_P] * 9 + [_i] * 4 + [_P, _P, _f, _f, _u64, _u64, _P]),
     "mmskin_linear_lane": (_i, [_P, _i, _P, _i, _P, _P, _P, _f, _u64, _u64, _P, _i, _i, _i, _i, _i, _P]),
     "mmskin_layernorm_forward_mixed": (_i, [_P] * 5 + [_i, _i, _f, _P]),
     "mmskin_flash_attention_forward": (_i, [_P] * 7 + [_i] * 4 + [_P, _i, _f, _i, _f, _u64, _u64, _P]),

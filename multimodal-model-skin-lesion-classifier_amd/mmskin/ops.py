@@ -353,22 +353,100 @@ class AttentionFn(torch.autograd.Function):
         q, k, v = _f32c(q), _f32c(k), _f32c(v)
         B, H, L, Dh = q.shape
         o = torch.empty_like(q)
+        ctx.rng = (float(drop_p), int(seed), int(offset))
+        ctx.rows = _rows_ok(L, Dh)
+        if ctx.rows:   # one wave per head, row log-sum-exp instead of the [B, H, L, L] probabilities
+            lse = torch.empty((B, H, L), device=q.device, dtype=torch.float32)
+            st = _i64x3(H * L * Dh, L * Dh, Dh)
+            call("mmskin_attention_rows_forward", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, L, Dh, st, st, Dh ** -0.5, *ctx.rng, stream())
+            ctx.save_for_backward(q, k, v, o, lse)
+            return o
         p = torch.empty((B, H, L, L), device=q.device, dtype=torch.float32)
         call("mmskin_attention_forward", ptr(q), ptr(k), ptr(v), ptr(o), ptr(p), B, H, L, Dh, float(drop_p), int(seed),
              int(offset), stream())
         ctx.save_for_backward(q, k, v, p)
-        ctx.rng = (float(drop_p), int(seed), int(offset))
         return o
 
     @staticmethod
     def backward(ctx, dO):
+        dO = _f32c(dO)
+        if ctx.rows:
+            q, k, v, o, lse = ctx.saved_tensors
+            B, H, L, Dh = q.shape
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            st = _i64x3(H * L * Dh, L * Dh, Dh)
+            call("mmskin_attention_rows_backward", ptr(dO), ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(dq), ptr(dk), ptr(dv), B, H, L, Dh,
+                 st, st, Dh ** -0.5, *ctx.rng, stream())
+            return dq, dk, dv, None, None, None
         q, k, v, p = ctx.saved_tensors
         B, H, L, Dh = q.shape
-        dO = _f32c(dO)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         call("mmskin_attention_backward", ptr(dO), ptr(q), ptr(k), ptr(v), ptr(p), ptr(dq), ptr(dk), ptr(dv), B, H, L,
              Dh, *ctx.rng, stream())
         return dq, dk, dv, None, None, None
+
+
+def _rows_ok(L, Dh):
+    """shapes of the one-wave-per-head attention kernels (mmskin_attention_rows_*)"""
+    return L <= 64 and Dh in (32, 64)
+
+
+def _i64x3(a, b, c):
+    import ctypes
+    return (ctypes.c_int64 * 3)(int(a), int(b), int(c))
+
+
+@no_second_order
+class AttentionPackedFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(Dh)) v straight on the packed [B, L, 3, H, Dh] output of a fused qkv Linear -> [B, L, H, Dh] (token-major,
+    what the output projection reads); the backward writes d(qkv) in the packed layout.  No permute / contiguous copies in either
+    direction (timm Attention.forward / DaViT WindowAttention with gradients: window attention of 49 tokens, Dh 32)."""
+
+    @staticmethod
+    def forward(ctx, qkv, drop_p, seed, offset):
+        _need_gpu(qkv, "attention_packed")
+        qkv = _f32c(qkv)
+        B, L, three, H, Dh = qkv.shape
+        o = torch.empty((B, L, H, Dh), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((B, H, L), device=qkv.device, dtype=torch.float32)
+        ctx.rng = (float(drop_p), int(seed), int(offset))
+        step = H * Dh * 4
+        qs, os_ = _i64x3(L * 3 * H * Dh, Dh, 3 * H * Dh), _i64x3(L * H * Dh, Dh, H * Dh)
+        base = qkv.data_ptr()
+        import ctypes
+        call("mmskin_attention_rows_forward", ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step), ptr(o),
+             ptr(lse), B, H, L, Dh, qs, os_, Dh ** -0.5, *ctx.rng, stream())
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        import ctypes
+        qkv, o, lse = ctx.saved_tensors
+        B, L, three, H, Dh = qkv.shape
+        dO = _f32c(dO)
+        dqkv = torch.empty_like(qkv)
+        step = H * Dh * 4
+        qs, os_ = _i64x3(L * 3 * H * Dh, Dh, 3 * H * Dh), _i64x3(L * H * Dh, Dh, H * Dh)
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        call("mmskin_attention_rows_backward", ptr(dO), ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step),
+             ptr(o), ptr(lse), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + step), ctypes.c_void_p(dbase + 2 * step), B, H, L, Dh,
+             qs, os_, Dh ** -0.5, *ctx.rng, stream())
+        return dqkv, None, None, None
+
+
+def attention_packed(qkv, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
+    """Attention on the packed output of a fused qkv Linear, qkv [B, L, 3, H, Dh] -> [B, L, H, Dh].  Picks, in order: the fused bf16
+    kernel (inference lane), the one-wave-per-head fp32 kernels reading the packed tensor in place (L <= 64, Dh 32 / 64, no mask /
+    bias: window attention with gradients), else attention_blhd on the three views."""
+    B, L, _, H, Dh = qkv.shape
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    if (qkv.is_cuda and qkv.dtype == torch.float32 and mask_add is None and bias is None and not causal and _rows_ok(L, Dh)
+            and not _flash_ok(q, k, v, mask_add, bias) and qkv.is_contiguous()):
+        p = dropout_p if training else 0.0
+        seed, offset = _dropout_state(p, B * H * L * L)
+        return AttentionPackedFn.apply(qkv, p, seed, offset)
+    return attention_blhd(q, k, v, dropout_p, training, mask_add, bias, causal)
 
 
 def _bmm(a, b, c, batch, M, N, K, sam, sak, sab, sbn, sbk, sbb, ldc, scb):

@@ -68,7 +68,7 @@ class _WindowAttention(nn.Module):
         Bw, L, C = xw.shape
         H = self.num_heads
         qkv = self.qkv(xw.reshape(Bw * L, C)).reshape(Bw, L, 3, H, C // H)
-        o = ops.attention_blhd(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+        o = ops.attention_packed(qkv)                 # reads the packed qkv tensor in place, writes token-major
         return self.proj(o.reshape(Bw * L, C)).reshape(Bw, L, C)
 
 

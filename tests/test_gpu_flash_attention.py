@@ -260,3 +260,52 @@ def test_linear_lane_fused_tail_matches_separate_ops():
         assert rel_err(ysm.cpu(), (xs @ ws.T + rs).cpu()) < 2e-2
     with pytest.raises(Exception):
         ops.linear_lane(x.float().requires_grad_(True), w, b)
+
+
+@pytest.mark.parametrize("B,H,L,Dh,p", [(3, 3, 49, 32, 0.0), (2, 2, 64, 64, 0.0), (5, 1, 7, 32, 0.0), (2, 3, 49, 32, 0.2)])
+def test_attention_rows_kernels_match_torch(B, H, L, Dh, p):
+    """One-wave-per-head fp32 attention (mmskin_attention_rows_*): forward and all three gradients against float64 torch math, through
+    both layouts -- separate [B, H, L, Dh] tensors (ops.attention) and the packed [B, L, 3, H, Dh] qkv tensor read in place
+    (ops.attention_packed).  With dropout: same mask as the unfused path (compared through the long-sequence ops on the same call)."""
+    g = torch.Generator().manual_seed(31 + L)
+    qkv = torch.randn(B, L, 3, H, Dh, generator=g)
+    dO = torch.randn(B, L, H, Dh, generator=g)
+
+    def ref(qkv64):
+        q, k, v = (qkv64[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        pr = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(Dh), -1)
+        return (pr @ v).permute(0, 2, 1, 3)
+    if p == 0.0:
+        r = qkv.double().requires_grad_(True)
+        want = ref(r)
+        want.backward(dO.double())
+        # packed layout
+        x = qkv.to(DEV).requires_grad_(True)
+        got = ops.attention_packed(x)
+        assert got.shape == (B, L, H, Dh)
+        got.backward(dO.to(DEV))
+        assert rel_err(got.detach().cpu(), want.detach().float()) < 1e-5
+        assert rel_err(x.grad.cpu(), r.grad.float()) < 2e-5
+        # separate [B, H, L, Dh] tensors
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous().to(DEV).requires_grad_(True) for i in range(3))
+        o2 = ops.attention(q, k, v)
+        o2.backward(dO.permute(0, 2, 1, 3).contiguous().to(DEV))
+        assert rel_err(o2.detach().permute(0, 2, 1, 3).cpu(), want.detach().float()) < 1e-5
+        for i, t in enumerate((q, k, v)):
+            assert rel_err(t.grad.permute(0, 2, 1, 3).cpu(), r.grad[:, :, i].float()) < 2e-5
+    else:
+        # dropout: the packed path and the [B, H, L, Dh] path draw element ((b*H + h)*L + i)*L + j of their call -- replay one call for both
+        state = list(ops._dropout_counter)
+        x = qkv.to(DEV).requires_grad_(True)
+        got = ops.attention_packed(x, p, True)
+        got.backward(dO.to(DEV))
+        ops._dropout_counter[:] = state
+        q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).contiguous().to(DEV).requires_grad_(True) for i in range(3))
+        seed, offset = ops._dropout_state(p, B * H * L * L)
+        o2 = ops.LongAttentionFn.apply(q, k, v, None, p, seed, offset, None, False)      # unfused GEMM -> softmax -> dropout -> GEMM chain
+        o2.backward(dO.permute(0, 2, 1, 3).contiguous().to(DEV))
+        assert rel_err(got.detach().cpu(), o2.detach().permute(0, 2, 1, 3).cpu()) < 1e-5
+        for i, t in enumerate((q, k, v)):
+            assert rel_err(x.grad[:, :, i].cpu(), t.grad.permute(0, 2, 1, 3).cpu()) < 2e-5
+        frac = float((got.detach() != ops.attention_packed(x.detach())).float().mean())
+        assert frac > 0.5      # dropout really changed the result
