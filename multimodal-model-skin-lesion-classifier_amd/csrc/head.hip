@@ -231,6 +231,78 @@ static int cvt_to_f32(const bf16_t* in, float* out, int64_t n, hipStream_t st) {
   return MMSKIN_OK;
 }
 
+// ---- Linear layers whose widths are not multiples of 64 (DaViT's 96 / 288-wide first stage over 200 704 tokens) on the bf16 GEMM
+// kernels: operands are converted into zero-padded bf16 copies (the conversion pass exists anyway), the GEMM runs on the padded
+// widths, and the result is un-padded while it is widened (+ bias / activation).  Zero pad columns contribute exact zeros.
+static inline int pad64(int v) { return (v + 63) / 64 * 64; }
+static inline bool linear_big_padded(int M, int K, int N) {
+  return M >= 2048 && K % 8 == 0 && N % 8 == 0 && K >= 32 && N >= 32 && !(K % 64 == 0 && N % 64 == 0);
+}
+// out [rows_pad][cols_pad] bf16 <- in [rows][cols] fp32, zeros elsewhere; one 16-byte chunk (8 values) per thread
+__global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t rows, int cols, int64_t rows_pad,
+                                       int cols_pad) {
+  const int cpr = cols_pad / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows_pad * cpr; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (r < rows && c < cols) {
+      const float4 a = *reinterpret_cast<const float4*>(in + r * cols + c), b = *reinterpret_cast<const float4*>(in + r * cols + c + 4);
+      o = make_uint4(f32_to_bf16_bits(a.x) | (f32_to_bf16_bits(a.y) << 16), f32_to_bf16_bits(a.z) | (f32_to_bf16_bits(a.w) << 16),
+                     f32_to_bf16_bits(b.x) | (f32_to_bf16_bits(b.y) << 16), f32_to_bf16_bits(b.z) | (f32_to_bf16_bits(b.w) << 16));
+    }
+    *reinterpret_cast<uint4*>(out + r * cols_pad + c) = o;
+  }
+}
+// out [rows][cols] fp32 <- act(in [rows][cols_pad] bf16 + bias); act 0 none / 1 ReLU / 2 exact GELU
+__global__ void bf16_unpad_bias_act_kernel(const bf16_t* __restrict__ in, const float* __restrict__ bias, float* __restrict__ out,
+                                           int64_t rows, int cols, int cols_pad, int act) {
+  const int cpr = cols / 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows * cpr; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    Chunk<bf16_t> v;
+    v.load(in + r * cols_pad + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v.v[e] + (bias ? bias[c + e] : 0.f);
+      if (act == 1) t = fmaxf(t, 0.f);
+      else if (act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
+      v.v[e] = t;
+    }
+    *reinterpret_cast<float4*>(out + r * cols + c) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+    *reinterpret_cast<float4*>(out + r * cols + c + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
+  }
+}
+// out[k][n] (bf16, row pitch out_pitch) = in[n][k] (fp32): the transposed weight inside a zero-filled padded matrix
+__global__ void transpose_f32_to_bf16_pitch_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols, int out_pitch) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[i][threadIdx.x] = in[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(int64_t)c * out_pitch + r] = (bf16_t)f32_to_bf16_bits(tile[threadIdx.x][i]);
+  }
+}
+static int cvt_to_bf16_pad(const float* in, bf16_t* out, int64_t rows, int cols, int64_t rows_pad, int cols_pad, hipStream_t st) {
+  const int64_t n = rows_pad * (cols_pad / 8);
+  int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, out, rows, cols, rows_pad, cols_pad);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+static int unpad_bias_act(const bf16_t* in, const float* bias, float* out, int64_t rows, int cols, int cols_pad, int act, hipStream_t st) {
+  const int64_t n = rows * (cols / 8);
+  int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(bf16_unpad_bias_act_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, bias, out, rows, cols, cols_pad, act);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 __global__ void relu_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = y[i] > 0.f ? dy[i] : 0.f;
@@ -1011,6 +1083,19 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
                           void* stream) {
   ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
   ARG_CHECK(relu >= 0 && relu <= 2, "linear_forward: activation %d (0 none, 1 ReLU, 2 exact GELU)", relu);
+  if (linear_bf16() && linear_big_padded(M, K, N)) {
+    const int Kp = pad64(K), Np = pad64(N);
+    ConvShape s = {M, 1, 1, Kp, Np, 1, 1, 1, 0};
+    const size_t xb = align_up((size_t)M * Kp * 2, 256), wb = align_up((size_t)Np * Kp * 2, 256), yb = align_up((size_t)M * Np * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb + yb));
+    if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
+    int rc;
+    if ((rc = cvt_to_bf16_pad(x, x16, M, K, M, Kp, ST(stream)))) return rc;
+    if ((rc = cvt_to_bf16_pad(w, w16, N, K, Np, Kp, ST(stream)))) return rc;
+    if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, y16, nullptr, nullptr, ST(stream), nullptr))) return rc;
+    return unpad_bias_act(y16, b, y, M, N, Np, relu, ST(stream));
+  }
   if (linear_big(M, K, N) && linear_bf16()) {
     // bf16 operands, fp32 accumulate; bias + activation + the widening to fp32 all happen in the GEMM epilogue
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
@@ -1130,6 +1215,31 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     g = dy_scratch;
   }
   int rc;
+  if (linear_bf16() && linear_big_padded(M, K, N)) {
+    const int Kp = pad64(K), Np = pad64(N);
+    ConvShape s = {M, 1, 1, Kp, Np, 1, 1, 1, 0};
+    const size_t gb = align_up((size_t)M * Np * 2, 256), xb = align_up((size_t)M * Kp * 2, 256), wb = align_up((size_t)Np * Kp * 2, 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + align_up(conv_wgrad_slab_bytes(s), 256)));
+    if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
+    float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
+    if ((rc = cvt_to_bf16_pad(g, g16, M, N, M, Np, st))) return rc;
+    if (dx) {
+      ARG_CHECK(w, "linear_backward: w required for dx");
+      HIP_CHECK_RET(hipMemsetAsync(w16, 0, (size_t)Np * Kp * 2, st));
+      hipLaunchKernelGGL(transpose_f32_to_bf16_pitch_kernel, dim3(ceil_div(K, 32), ceil_div(N, 32)), dim3(32, 8), 0, st, w, w16, N, K, Np);
+      HIP_CHECK_RET(hipGetLastError());
+      if ((rc = launch_conv_dgrad<bf16_t>(s, g16, w16, t16, (const bf16_t*)nullptr, st))) return rc;   // dx [M][Kp] in bf16, un-padded while widened
+      if ((rc = unpad_bias_act(t16, nullptr, dx, M, K, Kp, 0, st))) return rc;
+    }
+    if (dw) {
+      ARG_CHECK(x, "linear_backward: x required for dw");
+      if ((rc = cvt_to_bf16_pad(x, t16, M, K, M, Kp, st))) return rc;
+      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, t16, slab, dw, st, N, K))) return rc;   // reduces straight into the unpadded [N][K] gradient
+    }
+    if (db && (rc = colsum(g, db, M, N, st))) return rc;
+    return MMSKIN_OK;
+  }
   if (linear_big(M, K, N) && linear_bf16()) {
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
     const size_t gb = align_up((size_t)M * N * 2, 256), xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);

@@ -309,3 +309,28 @@ def test_attention_rows_kernels_match_torch(B, H, L, Dh, p):
             assert rel_err(x.grad[:, :, i].cpu(), t.grad.permute(0, 2, 1, 3).cpu()) < 2e-5
         frac = float((got.detach() != ops.attention_packed(x.detach())).float().mean())
         assert frac > 0.5      # dropout really changed the result
+
+
+@pytest.mark.parametrize("M,K,N", [(4096 + 24, 96, 288), (2048, 288, 96), (3000, 384, 96), (2048, 40, 72)])
+def test_linear_bf16_padded_widths(M, K, N):
+    """bf16-operand Linear with widths that are not multiples of 64 (DaViT stage 1: 96 / 288): zero-padded bf16 operand copies on the
+    MFMA GEMM kernels, un-padded while widening -- forward (+ bias, ReLU) and dx / dw / db against float64 math on the bf16-rounded
+    operands (the pad columns must contribute exact zeros)."""
+    ops.set_linear_dtype("bf16")
+    g = torch.Generator().manual_seed(M + K)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr = x.bfloat16().double(), w.bfloat16().double()
+    for relu in (False, True):
+        xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        y = ops.linear(xd, wd, bd, relu)
+        y.backward(dy.to(DEV))
+        ref = xr @ wr.T + b.double()
+        gg = dy.double() * ((y.detach().cpu() > 0) if relu else 1.0)     # the ReLU mask the backward really used (sign flips next to 0 are rounding)
+        if relu:
+            ref = ref.clamp_min(0)
+        assert rel_err(y.detach().cpu(), ref.float()) < 2.5e-2     # the GEMM result is staged in bf16 before bias / ReLU: 2^-9 of |y| <= 4
+        gr = gg.bfloat16().double()                      # the gradient operand is rounded to bf16 as well
+        assert rel_err(xd.grad.cpu(), (gr @ wr).float()) < 2e-2
+        assert rel_err(wd.grad.cpu(), (gr.T @ xr).float()) < 2e-2
+        assert rel_err(bd.grad.cpu(), gg.sum(0).float()) < 1e-4
