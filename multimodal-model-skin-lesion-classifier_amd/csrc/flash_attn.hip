@@ -37,6 +37,7 @@ struct FlashArgs {
   float scale, drop_p;
   int causal;
   uint64_t seed, offset;
+  int ablate;   // -DMMSKIN_ABLATE builds only (scripts/flash_ablate.py): bit0 K / V global loads after tile 0, bit1 softmax VALU work, bit2 MFMAs, bit3 K / V LDS stores
 };
 
 __device__ __forceinline__ uint64_t fa_mix64(uint64_t x) {
@@ -74,6 +75,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * BQ;
   const int L = p.L;
+#ifdef MMSKIN_ABLATE
+  const int abl = p.ablate;
+#else
+  constexpr int abl = 0;
+#endif
 
   // ---- Q fragments: lane (row l15 of this wave's 16, d = 32 ks + 8 g .. +7) as bf16; `scale` is applied to S in fp32
   uint4 qf[KS];
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
         badd[n][r] = (p.bias && kj < L && qi < L) ? p.bias[((int64_t)h * L + qi) * L + kj] : 0.f;
       }
     }
-    if (t + 1 < nt) load_tile(t + 1);   // in flight under this tile's MFMAs and softmax
+    if (t + 1 < nt && !(abl & 1)) load_tile(t + 1);   // in flight under this tile's MFMAs and softmax
 
     // ---- S = (scale Q) K^T : 4 key groups of 16
     f32x4_t s[4];
@@ -158,9 +164,16 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (16 * n + l15) * PITCH + (32 * ks + 8 * g) * 2);
-        s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[ks]), __builtin_bit_cast(bf16x8_t, kf), s[n], 0, 0, 0);
+        if (!(abl & 4)) s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, qf[ks]), __builtin_bit_cast(bf16x8_t, kf), s[n], 0, 0, 0);
       }
     }
+    if (abl & 2) {   // timing experiment: no softmax, P = S
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<uint16_t*>(Ps + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(s[n][r]);
+    } else {
     // ---- bias / masks; running max
     float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
     bool ok[4][4];
@@ -216,6 +229,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
     for (int i = 0; i < DN; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[i][r] *= alpha[r];
+    }
     // The P tile is wave-private and DS instructions of one wave execute in order: the reads below see the writes above
     // without a workgroup barrier (the compiler keeps the order: same LDS array).
     // ---- O += P V : A = P [16 q x 32 keys] (row reads), B = V [32 keys x 16 d] (transposing reads of the [key][d] tile)
@@ -229,11 +243,11 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
         const uint2 lo = lds_tr16_b64(Vs + r0 * PITCH + colb);
         const uint2 hi = lds_tr16_b64(Vs + r1 * PITCH + colb);
         const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        oacc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, vf), oacc[dn], 0, 0, 0);
+        if (!(abl & 4)) oacc[dn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, pf), __builtin_bit_cast(bf16x8_t, vf), oacc[dn], 0, 0, 0);
       }
     }
     if constexpr (NB == 2) {
-      if (t + 1 < nt) store_tile((t + 1) & 1);
+      if (t + 1 < nt && !(abl & 8)) store_tile((t + 1) & 1);
       __syncthreads();
     } else {
       __syncthreads();                       // every wave is done with this tile's K / V
@@ -288,6 +302,10 @@ int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, 
   a.v_sb = strides12[6]; a.v_sh = strides12[7]; a.v_sl = strides12[8];
   a.o_sb = strides12[9]; a.o_sh = strides12[10]; a.o_sl = strides12[11];
   a.scale = scale; a.drop_p = drop_p; a.causal = causal; a.seed = seed; a.offset = offset;
+  a.ablate = 0;
+#ifdef MMSKIN_ABLATE
+  { const char* e = getenv("MMSKIN_FLASH_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+#endif
   return io_dtype == MMSKIN_BF16 ? flash_launch<bf16_t>(a, Dh, (hipStream_t)stream) : flash_launch<float>(a, Dh, (hipStream_t)stream);
 }
 
