@@ -243,7 +243,9 @@ int mmskin_layernorm_forward_mixed(const float* x, const float* g, const float* 
                                    float eps, void* stream);
 /* Operand type of the large Linear GEMMs (rows >= 2048, 64-multiple widths: the transformer backbones' and BERT's
  * projections): MMSKIN_F32 = exact-f32 MFMA (default, parity mode), MMSKIN_BF16 = bf16 operands with fp32 accumulation
- * (BASELINE configs[3] is quoted in bf16).  Process-wide; the environment variable MMSKIN_LINEAR_DTYPE sets the initial value. */
+ * (BASELINE configs[3] is quoted in bf16); in that mode widths that are only multiples of 8 (DaViT's 96 / 288) run on the same kernels
+ * through zero-padded bf16 operand copies (mmskin_linear_forward / _backward; exact zeros from the pad columns).  Process-wide; the
+ * environment variable MMSKIN_LINEAR_DTYPE sets the initial value. */
 int mmskin_set_linear_dtype(int dtype);
 int mmskin_get_linear_dtype(void);
 /* y = a + b, b broadcast over the leading dimension when nb < n (residual sums, position embeddings) */
