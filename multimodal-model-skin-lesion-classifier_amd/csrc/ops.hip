@@ -274,6 +274,9 @@ int bn_apply(const T* x, const T* res, const float* scale, const float* shift, c
   size_t nch = rows * (C / EPC);
   int grid = ew_grid(nch);
   int mode = res ? (rscale ? 2 : 1) : 0;
+#ifdef MMSKIN_ABLATE   // `make ablate` only: upper bound of folding the plain BN + ReLU apply into its consumers (wrong results, valid timing)
+  { static const int abl = [] { const char* v = getenv("MMSKIN_BN_ABLATE"); return v ? atoi(v) : 0; }(); if ((abl & 1) && mode == 0 && relu) return MMSKIN_OK; }
+#endif
 #define LAUNCH(R, H) hipLaunchKernelGGL((bn_apply_kernel<T, R, H>), dim3(grid), dim3(EW_BLOCK), 0, st, x, res, scale, shift, rscale, rshift, y, mask_bits, nch, C / EPC, relu_cap)
   if (relu && relu_cap < 0.f) { if (mode == 2) LAUNCH(2, 2); else if (mode == 1) LAUNCH(2, 1); else LAUNCH(2, 0); }
   else if (relu) {
@@ -489,6 +492,9 @@ int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, co
   ARG_CHECK(C % EPC == 0, "bn_bwd_apply: C=%d", C);
   size_t nch = rows * (C / EPC);
   int grid = ew_grid(nch);
+#ifdef MMSKIN_ABLATE   // `make ablate` only: upper bound of folding the BN-backward apply into the dgrad / weight-gradient operand loads
+  { static const int abl = [] { const char* v = getenv("MMSKIN_BN_ABLATE"); return v ? atoi(v) : 0; }(); if ((abl & 2) && mask_mode == MASK_NONE && !dz_out) return MMSKIN_OK; }
+#endif
 #define LAUNCH(M, W) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, M, W>), dim3(grid), dim3(EW_BLOCK), 0, st, dy, x, ymask, scale, shift, cA, cB, cC, dx, dz_out, nch, C / EPC)
   if (mask_mode == MASK_FROM_X) { if (dz_out) LAUNCH(MASK_FROM_X, true); else LAUNCH(MASK_FROM_X, false); }
   else if (mask_mode == MASK_FROM_Y) { if (dz_out) LAUNCH(MASK_FROM_Y, true); else LAUNCH(MASK_FROM_Y, false); }
