@@ -157,10 +157,30 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream():
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream on the current device (raw handle: torch.cuda.current_stream() builds a Stream object
+    and resolves the device index in Python, ~8 us per op on a launch-bound step)"""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if get is not None and dev is not None:
+            _raw_stream = lambda: get(dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return ctypes.c_void_p(_raw_stream())
+
+
+_fns = {}
 
 
 def call(name, *args):
-    check(getattr(load(), name)(*args))
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc)
