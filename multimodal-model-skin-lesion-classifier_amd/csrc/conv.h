@@ -55,7 +55,11 @@ struct ConvGemmArgs {
   int Sy, Sx, OS;
   int OHf, OWf;
   int ncls, total_mblk, nblk_n;
+  int simple_src;      // 1x1 / stride 1 / no padding, one tap class: tile row m IS source pixel m (no per-row index arithmetic in the prologue)
   int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
+#ifdef MMSKIN_ABLATE
+  unsigned long long* stamps;   // in-kernel phase stamps (scripts/conv_stamps.py): [workgroup][8] s_memtime values, or null
+#endif
   TapClass cls[4];
 };
 

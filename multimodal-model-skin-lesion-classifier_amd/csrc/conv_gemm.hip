@@ -77,6 +77,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   unsigned char* Bs = As + NST * A_BYTES;
 
   const int tid = threadIdx.x;
+#ifdef MMSKIN_ABLATE
+  if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8] = clock64();
+#endif
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mblk = tile / p.nblk_n, nblk = tile - mblk * p.nblk_n;
   int ci = 0;
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   // thread for each of its rows (eight threads share a row; the divisions were most of a short-K workgroup's prologue)
   const int ab = a_dim * b_dim;
   int* s_src = s_tap + 64 + BM;   // [3][BM]: base offset, y, x
-  if (tid < BM) {
+  const bool simple_src = p.simple_src != 0;   // 1x1 / stride 1: no source-row table (in-kernel stamps: the prologue was a fifth of a short-K workgroup's life)
+  if (!simple_src && tid < BM) {
     const int m = m0 + tid;
     int base = 0, iy = -(1 << 20), ix = -(1 << 20);
     if (m < rows) {
@@ -118,7 +122,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int r = lr + PR * i;
-    a_base[i] = s_src[r]; a_iy[i] = s_src[BM + r]; a_ix[i] = s_src[2 * BM + r];
+    if (simple_src) {
+      const int m = m0 + r;
+      const bool in = m < rows;
+      a_base[i] = in ? m * p.Cpitch : 0; a_iy[i] = in ? 0 : -(1 << 20); a_ix[i] = 0;
+    } else {
+      a_base[i] = s_src[r]; a_iy[i] = s_src[BM + r]; a_ix[i] = s_src[2 * BM + r];
+    }
   }
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
   const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w) +
@@ -140,6 +150,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   constexpr int abl = 0;
 #endif
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifdef MMSKIN_ABLATE
+#define STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // The DMA is issued from inline asm: through the builtin, hipcc models it as an LDS store that may alias
 // every ds_read and drains s_waitcnt vmcnt(0) in front of the MFMA loop, which serialised load and
@@ -204,13 +219,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       __syncthreads();
     }
   } else {
+    STAMP(1);
     for (int kt = 0; kt < nk; ++kt) {
       LOAD_TILE(0);
+      if (kt == 0) STAMP(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (kt == 0) STAMP(3);
       COMPUTE_TILE(0);
       __syncthreads();   // every wave is done with the buffer before it is refilled / reused as C staging
     }
+    STAMP(4);
   }
 #undef COMPUTE_TILE
 #undef LOAD_TILE
@@ -246,6 +265,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       }
     }
   __syncthreads();
+  STAMP(5);
 
   constexpr int CH_PER_ROW = BN / EPC;
   constexpr int ROWS_PER_PASS = NT / CH_PER_ROW;
@@ -419,6 +439,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       } else if (!(abl & 8)) v.store(out_b + goffs[k]);
     }
   }
+  STAMP(6);
   if (p.stat_sum) {
     __syncthreads();                               // all rows of Cs consumed: the reduction buffer overlays it
     float* red = reinterpret_cast<float*>(Cs);     // [3][ROWS_PER_PASS][BN]
@@ -443,9 +464,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       if (p.stat_b_sq) { p.stat_b_sum[o] = s; p.stat_b_sq[o] = b3; }
     }
   }
+  STAMP(7);
+#undef STAMP
 }
 
 // ------------------------------------------------------------------------------------------ host
+#ifdef MMSKIN_ABLATE   // timing-experiment library only
+static unsigned long long* g_conv_stamps = nullptr;
+extern "C" void mmskin_debug_set_conv_stamps(void* device_ptr) { g_conv_stamps = reinterpret_cast<unsigned long long*>(device_ptr); }
+#endif
 template <typename T, int BM, int BN, int WMv, int WNv, int EPI, int NST>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   constexpr int NT = 64 * WMv * WNv;
@@ -476,6 +503,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   a.ablate = 0;
 #ifdef MMSKIN_ABLATE
   { const char* abl = getenv("MMSKIN_CONV_ABLATE"); a.ablate = abl ? atoi(abl) : 0; }
+  a.stamps = g_conv_stamps;
 #endif
   const bool tr = a.ep_gamma || a.res_f32 || a.ep_drop_p > 0.f;   // transformer-residual epilogue
   const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32 || tr;
@@ -562,6 +590,7 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
       c.offy[t] = (int8_t)(r - s.pad); c.offx[t] = (int8_t)(q - s.pad); c.wtap[t] = (int8_t)t;
     }
   finish_classes(a);
+  a.simple_src = (s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0) ? 1 : 0;
   return dispatch_conv_gemm<T>(a, st);
 }
 
@@ -641,6 +670,7 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
     for (int j = i; j > 0 && a.cls[j].ntaps > a.cls[j - 1].ntaps; --j) { TapClass t = a.cls[j]; a.cls[j] = a.cls[j - 1]; a.cls[j - 1] = t; }
   finish_classes(a);
   if (fuse) fuse->rows_written = a.total_mblk;
+  a.simple_src = (s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0 && a.ncls == 1) ? 1 : 0;
   return dispatch_conv_gemm<T>(a, st);
 }
 
