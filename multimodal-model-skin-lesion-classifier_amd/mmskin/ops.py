@@ -106,7 +106,8 @@ def frozen_bf16(*ws):
         w16 = (ws[0] if len(ws) == 1 else torch.cat([w.reshape(w.shape[0], -1) for w in ws], 0)).to(torch.bfloat16).contiguous()
     if len(_frozen_cache) > 4096:
         _frozen_cache.clear()
-    _frozen_cache[key] = (vers, tuple(weakref.ref(w) for w in ws), w16)
+    drop = lambda _ref, key=key: _frozen_cache.pop(key, None)       # a source tensor died (model deleted / moved): free its bf16 copy too
+    _frozen_cache[key] = (vers, tuple(weakref.ref(w, drop) for w in ws), w16)
     return w16
 
 
