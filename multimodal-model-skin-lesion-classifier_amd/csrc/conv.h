@@ -75,6 +75,7 @@ struct WgradArgs {
   int ntaps;
   int M, m_per_split, nsplit;
   int nblk_o, nblk_k;  // tiles over Cout / Ktot
+  int simple1x1;       // host-side selector: 1x1 / stride 1 / no padding (gathered-input row m IS pixel m)
   int ablate;          // timing experiments only: bit0 skip X loads, bit1 skip Y loads, bit2 skip MFMA+LDS reads, bit3 skip slab store, bit4 skip LDS writes
   int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
 };

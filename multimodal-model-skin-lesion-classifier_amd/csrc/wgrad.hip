@@ -99,7 +99,9 @@ __device__ __forceinline__ void wg_compute(const unsigned char* Xb, const unsign
 // barrier-to-barrier interval carries >= 16 MFMAs per wave and 16-32 KB of loads (a 64x64 tile with 32
 // rows per step was latency-bound at 48 TF/s).
 // PF = stages kept in flight in registers (1 or 2).
-template <typename T, int BO, int BKK, int MSF, int PF>
+// S1: 1x1 / stride 1 / no padding -- the gathered-input row of pixel m is row m: no pixel stepping and no bounds tests in the stage loop
+// (~5 VALU per chunk and stage instead of ~25; a compile-time variant: the same test as a run-time flag cost more than it saved)
+template <typename T, int BO, int BKK, int MSF, int PF, bool S1 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
   constexpr int EPC = DT<T>::EPC, MS = WG<T>::MS * MSF;
   constexpr int PX = BO * (int)sizeof(T), PY = BKK * (int)sizeof(T);
@@ -169,7 +171,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     R = *reinterpret_cast<const u32x4_t*>(m < m_end ? src : zero_page);                                \
   }
 #define LOAD_Y(i, R)                                                                                   \
-  {                                                                                                    \
+  { if constexpr (S1) {                                                                                \
+    const int m = m_stage + y_row[i];                                                                  \
+    const unsigned char* src = in_b + ((int64_t)m * p.Cpitch + y_c[i]) * (int)sizeof(T);               \
+    R = *reinterpret_cast<const u32x4_t*>(m < m_end ? src : zero_page);                                \
+  } else {                                                                                             \
     const int m = m_stage + y_row[i];                                                                  \
     const int iy = y_oy[i] * p.Sy + y_dy[i], ix = y_ox[i] * p.Sx + y_dx[i];                            \
     const bool ok = m < m_end && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;       \
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     const int ny = y_oy[i] + qy;                                                                       \
     const int qi = (ny * inv_oh) >> 16;                                                                \
     y_ox[i] = nx; y_oy[i] = ny - qi * OHr; y_img[i] += qi;                                             \
-  }
+  } }
 #define LOAD_STAGE(S)                                                                                  \
   do {                                                                                                 \
     if (!(abl & 1)) { LOAD_X(0, rx##S##0) if constexpr (NX > 1) LOAD_X(1 % NX, rx##S##1)               \
@@ -453,7 +459,9 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
   int grid = a.nblk_o * a.nblk_k * a.nsplit;
   // two-deep prefetch measured no faster in isolation and slower inside the training step (224 VGPRs)
   static const int pf = [] { const char* v = getenv("MMSKIN_WGRAD_PF"); return v ? atoi(v) : 1; }();
+  static const int s1 = [] { const char* v = getenv("MMSKIN_WGRAD_S1"); return v ? atoi(v) : 1; }();
   if (pf == 2) hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF, 2>), dim3(grid), dim3(256), 0, st, a);
+  else if (s1 && a.simple1x1 && sizeof(T) == 2 && BO >= 64 && BKK >= 64 && BO + BKK >= 192) hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF, 1, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((wgrad_kernel<T, BO, BKK, MSF, 1>), dim3(grid), dim3(256), 0, st, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -701,6 +709,7 @@ int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* sla
   a.Cout = s.Cout; a.Ktot = s.kh * s.kw * s.Cin;
   a.Sy = s.stride; a.Sx = s.stride; a.ntaps = s.kh * s.kw;
   a.M = s.N * a.OH * a.OW;
+  a.simple1x1 = (s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0) ? 1 : 0;
   for (int r = 0; r < s.kh; ++r)
     for (int q = 0; q < s.kw; ++q) {
       a.offy[r * s.kw + q] = (int8_t)(r - s.pad);
