@@ -331,26 +331,29 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
       if (use_side) {
         HIP_CHECK_RET(hipEventRecord(p.side.f_ready, st));
         HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.f_ready, 0));
+        int nrows_d = 0;
         if ((rc = launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
-                                     training ? stat_b_sum : nullptr, training ? stat_b_sq : nullptr, p.side.s))) return rc;
-        if ((rc = bn_coeffs_on(d, conv_fwd_stat_rows(d.s), stat_b_sum, stat_b_sq,
+                                     training ? stat_b_sum : nullptr, training ? stat_b_sq : nullptr, p.side.s, nullptr, &nrows_d))) return rc;
+        if ((rc = bn_coeffs_on(d, nrows_d, stat_b_sum, stat_b_sq,
                                reinterpret_cast<double*>(ws + p.off_red_b), p.side.s))) return rc;
         HIP_CHECK_RET(hipEventRecord(p.side.f_done, p.side.s));
       } else {
+        int nrows_d = 0;
         PROF(K_CONV_FWD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)),
              launch_conv_fwd<T>(d.s, in, wf + d.wf_off, reinterpret_cast<T*>(ws + d.x_off),
-                                training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
-        if ((rc = bn_coeffs(d, conv_fwd_stat_rows(d.s)))) return rc;
+                                training ? stat_sum : nullptr, training ? stat_sq : nullptr, st, nullptr, &nrows_d));
+        if ((rc = bn_coeffs(d, nrows_d))) return rc;
       }
     }
     for (int i = 0; i < nu; ++i) {
       Unit& u = p.units[b.units[i]];
       T* x = reinterpret_cast<T*>(ws + u.x_off);
       T* y = reinterpret_cast<T*>(ws + u.y_off);
+      int nrows_u = 0;   // statistics row blocks this launch wrote (the launcher picks the tile height)
       PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
            launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
-                              training ? stat_sq : nullptr, st));
-      if ((rc = bn_coeffs(u, conv_fwd_stat_rows(u.s)))) return rc;
+                              training ? stat_sq : nullptr, st, nullptr, &nrows_u));
+      if ((rc = bn_coeffs(u, nrows_u))) return rc;
       float* coef = reinterpret_cast<float*>(ws + u.coef_off);
       const int C = u.s.Cout;
       if (i + 1 < nu) {

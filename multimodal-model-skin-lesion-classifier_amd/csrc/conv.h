@@ -56,6 +56,9 @@ struct ConvGemmArgs {
   int OHf, OWf;
   int ncls, total_mblk, nblk_n;
   int simple_src;      // 1x1 / stride 1 / no padding, one tap class: tile row m IS source pixel m (no per-row index arithmetic in the prologue)
+  uint64_t in_bytes;   // size of the gather source in bytes (the pipelined kernel's buffer descriptor: reads past it return zeros); 0 = not set
+  int bm_step;         // valid rows per row block (= the tile height except for the pipelined kernel's 196-of-224-row tiles); set by finish_classes
+  int pipe_ok;         // the caller can take a row-block count that differs from ceil(rows / 128) (statistics slabs), so any tile height may be chosen
   int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
 #ifdef MMSKIN_ABLATE
   unsigned long long* stamps;   // in-kernel phase stamps (scripts/conv_stamps.py): [workgroup][8] s_memtime values, or null
@@ -95,8 +98,10 @@ struct FwdFuse {
 };
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
-                    float* stat_sq, hipStream_t st, const FwdFuse* fuse = nullptr);
-// number of stat partial rows the forward launch produces (rows of stat_sum / stat_sq)
+                    float* stat_sq, hipStream_t st, const FwdFuse* fuse = nullptr, int* stat_rows_out = nullptr);
+// number of stat partial rows the forward launch produces (rows of stat_sum / stat_sq) when the caller passes no stat_rows_out;
+// with stat_rows_out the launcher may pick a taller tile and reports the (smaller) row count there -- the slabs sized for
+// conv_fwd_stat_rows() always suffice
 int conv_fwd_stat_rows(const ConvShape& s);
 
 // Optional epilogue fusion for launch_conv_dgrad (see ConvGemmArgs::ep_*): partial slabs use the

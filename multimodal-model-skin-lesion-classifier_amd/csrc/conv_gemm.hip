@@ -42,14 +42,17 @@ template <int BM> constexpr int tap_lds_bytes() { return (64 + 4 * BM) * 4; }
 // 256 bytes of zeros in global memory: the source of every out-of-image (padding) tap.
 __device__ uint4 g_zero_page[16];
 
+// NST == 8 selects the 8-phase pipelined main loop (PIPE): two 64 KB stages of [A: 2 wave rows x 128 tile rows][B: 256 rows] x 128 B
+// plus one int4 per K-tile (source offset, tap index, weight offset) behind the tap / row tables.
+constexpr int KT_LDS_BYTES = 2048;   // <= 128 K-tiles
 template <int BM, int BN, typename T, int NST, int NT = 256> constexpr int conv_gemm_lds_bytes() {
-  constexpr int ab = NST * (BM + BN) * 128;
+  constexpr int ab = NST == 8 ? 2 * (256 + BN) * 128 : NST * (BM + BN) * 128;
   constexpr int cpitch = BN * (int)sizeof(T) + 16;
   constexpr int rows_per_pass = NT / (BN / DT<T>::EPC);
   constexpr int cs = BM * cpitch;                       // C staging; the stat reduction buffer overlays it
   constexpr int red = 3 * rows_per_pass * BN * 4;
   constexpr int m1 = ab > cs ? ab : cs;
-  return tap_lds_bytes<BM>() + (m1 > red ? m1 : red);
+  return tap_lds_bytes<BM>() + (NST == 8 ? KT_LDS_BYTES : 0) + (m1 > red ? m1 : red);
 }
 
 // EPI = 0: plain epilogue (forward conv: store + BN partial sums); EPI = 1: addend and/or the fused
@@ -68,9 +71,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   constexpr int AP = BM / PR, BP = BN / PR;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   constexpr int CPITCH = BN * (int)sizeof(T) + 16;
-  constexpr int TAP_LDS_BYTES = tap_lds_bytes<BM>();
+  constexpr bool PIPE = NST == 8;
+  constexpr int TAP_LDS_BYTES = tap_lds_bytes<BM>() + (PIPE ? KT_LDS_BYTES : 0);
   static_assert(WAVES_M * WAVES_N == 4 || WAVES_M * WAVES_N == 8, "4 or 8 waves");
-  static_assert(BM <= NT && BN <= NT && BM % PR == 0 && BN % PR == 0, "tile / thread mismatch");
+  static_assert(PIPE || (BM <= NT && BN <= NT && BM % PR == 0 && BN % PR == 0), "tile / thread mismatch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* s_tap = reinterpret_cast<int*>(smem);
   unsigned char* As = smem + TAP_LDS_BYTES;
@@ -87,7 +91,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
     if (mblk >= p.cls[i].mblk_start) ci = i;
   const int a_dim = p.cls[ci].a_dim, b_dim = p.cls[ci].b_dim;
   const int ntaps = p.cls[ci].ntaps, rows = p.cls[ci].rows;
-  const int m0 = (mblk - p.cls[ci].mblk_start) * BM;
+  // PIPE tiles may use fewer valid rows than they compute (bm_step <= BM): 196-row tiles (one 14 x 14 image) put the layer-3 / 4
+  // convolutions of a 256-image batch on exactly 256 / 512 / 1024 workgroups instead of 196 / 392 / 784
+  const int bm_step = PIPE ? p.bm_step : BM;
+  const int m0 = (mblk - p.cls[ci].mblk_start) * bm_step;
   const int n0 = nblk * BN;
   const int C = p.C, IH = p.IH, IW = p.IW;
 
@@ -101,8 +108,40 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   // thread for each of its rows (eight threads share a row; the divisions were most of a short-K workgroup's prologue)
   const int ab = a_dim * b_dim;
   int* s_src = s_tap + 64 + BM;   // [3][BM]: base offset, y, x
-  const bool simple_src = p.simple_src != 0;   // 1x1 / stride 1: no source-row table (in-kernel stamps: the prologue was a fifth of a short-K workgroup's life)
-  if (!simple_src && tid < BM) {
+  int pipe_min_toff = 0;   // PIPE: most negative tap offset of this class (elements)
+  const bool simple_src = !PIPE && p.simple_src != 0;   // 1x1 / stride 1: no source-row table (in-kernel stamps: the prologue was a fifth of a short-K workgroup's life)
+  if constexpr (PIPE) {
+    // [0][BM] source offset of the row's pixel (elements), [1][BM] bit t = tap t of this row lies inside the image
+    if (tid < BM) {
+      const int m = m0 + tid;
+      int base = 0;
+      uint32_t mask = 0;
+      if (tid < bm_step && m < rows) {
+        const int img = m / ab, rem = m - img * ab;
+        const int a = rem / b_dim, b = rem - a * b_dim;
+        const int iy = a * p.Sy, ix = b * p.Sx;
+        base = ((img * IH + iy) * IW + ix) * p.Cpitch;
+        for (int t = 0; t < ntaps; ++t) {
+          const int y = iy + p.cls[ci].offy[t], x = ix + p.cls[ci].offx[t];
+          mask |= ((unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW) ? (1u << t) : 0u;
+        }
+      }
+      s_src[tid] = base; s_src[BM + tid] = (int)mask;
+    }
+    // one int4 per K-tile (C % 64 == 0: a K-tile never straddles two taps), in BYTES: gather offset above the most negative tap
+    // offset (the buffer descriptor's base carries that one, so the scalar offset of the DMA is never negative), tap bit, weight-row offset
+    for (int t = 0; t < ntaps; ++t) {
+      const int toff = (p.cls[ci].offy[t] * IW + p.cls[ci].offx[t]) * p.Cpitch;
+      pipe_min_toff = toff < pipe_min_toff ? toff : pipe_min_toff;
+    }
+    int4* s_kt = reinterpret_cast<int4*>(smem + tap_lds_bytes<BM>());
+    const int cpt = C / BK, nkt = ntaps * cpt;
+    for (int kt = tid; kt < nkt; kt += NT) {
+      const int t = kt / cpt, c0 = (kt - t * cpt) * BK;
+      const int oy = p.cls[ci].offy[t], ox = p.cls[ci].offx[t], wt = p.cls[ci].wtap[t];
+      s_kt[kt] = make_int4(((oy * IW + ox) * p.Cpitch - pipe_min_toff + c0) * (int)sizeof(T), 1 << t, (wt * C + c0) * (int)sizeof(T), 0);
+    }
+  } else if (!simple_src && tid < BM) {
     const int m = m0 + tid;
     int base = 0, iy = -(1 << 20), ix = -(1 << 20);
     if (m < rows) {
@@ -120,7 +159,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   const int lr = tid >> 3, jc = tid & 7;
   int a_base[AP], a_iy[AP], a_ix[AP];
 #pragma unroll
-  for (int i = 0; i < AP; ++i) {
+  for (int i = 0; i < (PIPE ? 0 : AP); ++i) {
     const int r = lr + PR * i;
     if (simple_src) {
       const int m = m0 + r;
@@ -207,7 +246,189 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       }                                                                                        \
   } while (0)
 
-  if constexpr (NST == 2) {
+  if constexpr (PIPE) {
+    // ---- 8-phase pipelined main loop (MI355X playbook: LDS-DMA ring with COUNTED vmcnt, raw s_barrier, two waves per SIMD in
+    // opposite roles).  Wave row 0 (waves 0-3) and wave row 1 (waves 4-7; wave w and w + 4 share a SIMD) run half a phase apart:
+    // while one group issues its 16-MFMA cluster the other reads fragments from LDS and issues the LDS-DMA of a unit that is needed
+    // 5 - 6 phases later.  A K-tile (64 deep) is four phases; its operands are four 16 KB units
+    //   A0 = fragment rows 0-3 of both wave rows   B0 = channels 0-31 of every wave column   (first read in phase 0)
+    //   B1 = channels 32-63                                                                  (phase 1)
+    //   A1 = fragment rows 4..FM-1                                                           (phase 2)
+    // in two stages (K-tile parity).  Unit sequence q = 4t + {A0,B0,B1,A1}; phase g = 4t + ph issues q = g + 6.  Fragments stay in
+    // registers across the phases that reuse them (A0: ph 0-1, B0: ph 0+3, B1: ph 1-2, A1: ph 2-3).
+    // The load side is kept to a few instructions per phase because its ISSUE time (not bandwidth) is what must fit under the other
+    // group's 256-cycle MFMA cluster: operands arrive through `buffer_load_dwordx4 ... offen lds` -- the per-lane part of the address
+    // is a loop-invariant 32-bit VGPR offset, the K-tile's offset is the instruction's SCALAR offset, and a row whose tap lies outside
+    // the image (or past the tile's valid rows) gets an out-of-range offset, for which the buffer unit writes zeros: no zero page, no
+    // 64-bit address arithmetic, three VALU instructions per gathered row and none for the weights.
+    static_assert(sizeof(T) == 2 && WAVES_M == 2 && WAVES_N == 4 && BN == 256 && FM >= 5 && FM <= 8, "PIPE tile");
+    constexpr int STAGE = (256 + BN) * 128;
+    constexpr uint32_t OOB = 0xF0000000u;   // >= any num_records the launcher admits
+    typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
+    const int4* s_kt = reinterpret_cast<const int4*>(smem + tap_lds_bytes<BM>());
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)As;
+    const int NQ = 4 * nk;
+    const int lane_ = tid & 63;
+    // gather rows of this thread: unit u (A0 / A1), wave row i -> tile row i * WM + u * 64 + lr
+    uint32_t pa_off[2][2], pa_mask[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int local = u * 64 + lr;
+        const bool okr = local < WM;
+        const int trow = okr ? i * WM + local : 0;
+        pa_off[u][i] = (uint32_t)(s_src[trow] + sc * EPC) * (uint32_t)sizeof(T);
+        pa_mask[u][i] = okr ? (uint32_t)s_src[BM + trow] : 0u;
+      }
+    const int rho0 = (wid_u >> 2) * 64 + (wid_u & 3) * 8;                 // first B row of this wave's 8-row DMA piece (unit 0, pass 0)
+    const uint32_t pb_off = (uint32_t)((rho0 + (lane_ >> 3)) * p.wrow + sc * EPC) * (uint32_t)sizeof(T);
+    const uint32_t w32 = (uint32_t)(32 * p.wrow) * (uint32_t)sizeof(T);
+    const uint32_t dstA = lds0 + wid_u * 8 * 128, dstB = lds0 + 256 * 128 + rho0 * 128;
+    srd_t srdA, srdB;
+    {
+      const uint64_t ba = (uint64_t)(uintptr_t)in_b + (int64_t)pipe_min_toff * (int)sizeof(T);
+      const uint64_t bb = (uint64_t)(uintptr_t)p.w + (uint64_t)n0 * p.wrow * sizeof(T);
+      srdA = srd_t{(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, (uint32_t)p.in_bytes - (uint32_t)(pipe_min_toff * (int)sizeof(T)), 0x00020000u};   // the range check covers voffset + soffset from the biased base
+      srdB = srd_t{(uint32_t)bb, (uint32_t)(bb >> 32) & 0xffffu, 0xE0000000u, 0x00020000u};
+    }
+    uint32_t s_zero;   // opaque scalar zero: scalar offsets handed to the DMA are SALU results (a VALU-written SGPR needs 5 wait states before a VMEM reads it)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(s_zero));
+// two DMA pieces (1 KB each, 8 tile rows) of one unit; M0 = LDS byte address of the piece (one wait state after the M0 write)
+#define BLDS2(v0, v1, srd, so0, so1, d0, d1)                                                               \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen lds\n\t"               \
+               "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"                   \
+               ::"s"((uint32_t)(d0)), "s"((uint32_t)(d1)), "v"((uint32_t)(v0)), "v"((uint32_t)(v1)), "s"(srd), \
+               "s"((uint32_t)(so0)), "s"((uint32_t)(so1)) : "memory")
+#define ISSUE_A(u, ka, kbit, sel)                                                             \
+  if (!(abl & 1)) {                                                                           \
+    const uint32_t v0_ = (pa_mask[u][0] & (kbit)) ? pa_off[u][0] : OOB;                       \
+    const uint32_t v1_ = (pa_mask[u][1] & (kbit)) ? pa_off[u][1] : OOB;                       \
+    const uint32_t so_ = (ka) + s_zero;                                                       \
+    BLDS2(v0_, v1_, srdA, so_, so_, dstA + (sel) + ((u) * 64) * 128, dstA + (sel) + (128 + (u) * 64) * 128); \
+  }
+#define ISSUE_B(u, kw, sel)                                                                   \
+  if (!(abl & 2)) {                                                                           \
+    BLDS2(pb_off, pb_off, srdB, (kw) + s_zero + (u) * w32, (kw) + (4 + (u)) * w32, dstB + (sel) + ((u) * 32) * 128, dstB + (sel) + (128 + (u) * 32) * 128); \
+  }
+#define WAIT_VM(rem)                                                            \
+  do {                                                                          \
+    const int r_ = (rem);                                                       \
+    if (abl & 64) break;                                                        \
+    if (r_ >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
+    else if (r_ == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+    else if (r_ == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
+  } while (0)
+#define BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+    STAMP(1);
+    {   // prologue: units 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
+      const int4 k0 = s_kt[0];
+      const uint32_t a0_ = RFL(k0.x), b0_ = RFL(k0.y), w0_ = RFL(k0.z);
+      ISSUE_A(0, a0_, b0_, 0) ISSUE_B(0, w0_, 0) ISSUE_B(1, w0_, 0) ISSUE_A(1, a0_, b0_, 0)
+      if (nk > 1) { const int4 k1p = s_kt[1]; const uint32_t a1_ = RFL(k1p.x), b1_ = RFL(k1p.y), w1_ = RFL(k1p.z); ISSUE_A(0, a1_, b1_, STAGE) ISSUE_B(0, w1_, STAGE) }
+      STAMP(2);
+      WAIT_VM(NQ - 3);   // A0, B0, B1 of K-tile 0 have landed
+      BAR();
+      STAMP(3);
+    }
+    // Synchronisation: ONE barrier per phase.  Wave row 0 runs  load(p) | barrier | mfma(p),  wave row 1  barrier | load(p) | mfma(p):
+    // between two barriers group 0 does mfma(p) + load(p+1) and group 1 load(p) + mfma(p), so each SIMD's matrix pipe alternates
+    // between its two waves without a second rendezvous (with load longer than the MFMA cluster the two-barrier form idles the pipe for
+    // the difference in EVERY half phase; this one only for what the two halves do not cover together).
+    //   RAW: group 0 reads unit q in phase need(q) <= q - 1, between barriers need-1 and need; group 1's last wait before that
+    //        barrier is the one of phase need - 2  ->  phase g waits until everything up to unit g + 3 has landed (3 units in flight).
+    //   WAR: a region is refilled >= 2 phases after its last fragment read; those reads have returned (lgkmcnt before the MFMAs
+    //        that consume them) before the reading group's next barrier, which precedes either group's refill.
+    const bool grp1 = wid_u >= 4;
+    const int off0 = ((g) ^ sw) << 4, off1 = ((4 + g) ^ sw) << 4;
+    const unsigned char* Ard = As + (wm * 128 + l15) * 128;              // A region: [wave row][128 rows]
+    const unsigned char* Brd = As + 256 * 128 + (wn * 64 + l15) * 128;   // B region
+    uint4 fa[4][2], fb0[2][2], fb1[2][2];
+#ifdef MMSKIN_ABLATE
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fa[j][s] = make_uint4(0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { fb0[i][s] = make_uint4(0x3c003c00u, 0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u); fb1[i][s] = fb0[i][s]; }
+    }
+#endif
+    uint32_t ka1, kb1, kw1;   // K-tile t + 1: gather offset, tap bit, weight offset (scalars)
+    { const int4 k1v = s_kt[nk > 1 ? 1 : 0]; ka1 = RFL(k1v.x); kb1 = RFL(k1v.y); kw1 = RFL(k1v.z); }
+#define LDSQ(ptr) (*reinterpret_cast<const uint4*>(ptr))
+#define MMA_BLOCK(FB, IB, NJ, JB)                                                        \
+  if (!(abl & 4)) {                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                        \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                      \
+        _Pragma("unroll") for (int j = 0; j < (NJ); ++j) Mma<T>::run(FB[i][s], fa[j][s], acc[(IB) + i][(JB) + j]); \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+  }
+// One K-tile = four phases.  STEADY = 1: every unit issued from these phases exists and three units stay in flight (no tail
+// arithmetic in the loop body).  (Unrolling by the stage parity made hipcc rename the accumulators between the two bodies:
+// 31 v_mov_b64 per K-tile and spills; the stage offset costs four v_add per K-tile instead.)
+#define PIPE_KTILE(STEADY)                                                                                              \
+  {                                                                                                                     \
+    const int sel = (t & 1) * STAGE, seln = STAGE - sel;                                                                \
+    const int g4 = 4 * t;                                                                                               \
+    const int4 k2v = s_kt[(STEADY) || t + 2 < nk ? t + 2 : nk - 1];                                                     \
+    const unsigned char* A0p = Ard + sel + off0; const unsigned char* A1p = Ard + sel + off1;                           \
+    const unsigned char* B0p = Brd + sel + off0; const unsigned char* B1p = Brd + sel + off1;                           \
+    /* ---- phase 0: (A0, B0) */                                                                                        \
+    if (grp1) BAR();                                                                                                    \
+    if (!(abl & 32)) {                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) { fb0[i][0] = LDSQ(B0p + i * 2048); fb0[i][1] = LDSQ(B1p + i * 2048); } \
+      __builtin_amdgcn_sched_barrier(0);                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) { fa[j][0] = LDSQ(A0p + j * 2048); fa[j][1] = LDSQ(A1p + j * 2048); } \
+    }                                                                                                                   \
+    if ((STEADY) || t + 1 < nk) { ISSUE_B(1, kw1, seln) }                                                               \
+    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 4 - g4);                                                                  \
+    if (!grp1) BAR();                                                                                                   \
+    MMA_BLOCK(fb0, 0, 4, 0)                                                                                             \
+    /* ---- phase 1: (A0, B1) */                                                                                        \
+    if (grp1) BAR();                                                                                                    \
+    const uint32_t ka2 = RFL(k2v.x), kb2 = RFL(k2v.y), kw2 = RFL(k2v.z);                                                \
+    if (!(abl & 32)) {                                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) { fb1[i][0] = LDSQ(B0p + (2 + i) * 2048); fb1[i][1] = LDSQ(B1p + (2 + i) * 2048); } \
+    }                                                                                                                   \
+    if ((STEADY) || t + 1 < nk) { ISSUE_A(1, ka1, kb1, seln) }                                                          \
+    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 5 - g4);                                                                  \
+    if (!grp1) BAR();                                                                                                   \
+    MMA_BLOCK(fb1, 2, 4, 0)                                                                                             \
+    /* ---- phase 2: (A1, B1) */                                                                                        \
+    if (grp1) BAR();                                                                                                    \
+    if (!(abl & 32)) {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < FM - 4; ++j) { fa[j][0] = LDSQ(A0p + (4 + j) * 2048); fa[j][1] = LDSQ(A1p + (4 + j) * 2048); } \
+    }                                                                                                                   \
+    if ((STEADY) || t + 2 < nk) { ISSUE_A(0, ka2, kb2, sel) }                                                           \
+    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 6 - g4);                                                                  \
+    if (!grp1) BAR();                                                                                                   \
+    MMA_BLOCK(fb1, 2, FM - 4, 4)                                                                                        \
+    /* ---- phase 3: (A1, B0) */                                                                                        \
+    if (grp1) BAR();                                                                                                    \
+    if ((STEADY) || t + 2 < nk) { ISSUE_B(0, kw2, sel) }                                                                \
+    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 7 - g4);                                                                  \
+    if (!grp1) BAR();                                                                                                   \
+    MMA_BLOCK(fb0, 0, FM - 4, 4)                                                                                        \
+    ka1 = ka2; kb1 = kb2; kw1 = kw2;                                                                                    \
+  }
+    int t = 0;
+    for (; t + 2 < nk; ++t) PIPE_KTILE(1)
+    for (; t < nk; ++t) PIPE_KTILE(0)
+    BAR();   // every wave is done with the ring before it becomes the C staging buffer
+    STAMP(4);
+#undef PIPE_KTILE
+#undef MMA_BLOCK
+#undef LDSQ
+#undef RFL
+#undef BAR
+#undef WAIT_VM
+#undef ISSUE_B
+#undef ISSUE_A
+#undef BLDS2
+  } else if constexpr (NST == 2) {
     if (nk > 0) LOAD_TILE(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my part of tile 0 has landed ...
     __syncthreads();                                   // ... and so has everybody else's
@@ -317,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   // dependent load->store chain per row (the fused epilogue was running at ~3 TB/s that way).
   constexpr int NR = BM / ROWS_PER_PASS;
   constexpr int EG_MAX = EPI == 6 ? 2 : 4;   // profile 6 holds 32 B of fp32 residual per row in flight: two rows keep it at the main loop's register count
-  constexpr int EG = NR < EG_MAX ? NR : EG_MAX;
+  constexpr int EG = NR < EG_MAX ? NR : (NR % EG_MAX == 0 ? EG_MAX : 2);
   static_assert(NR % EG == 0, "row groups");
   const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_page);
   for (int grp = 0; grp < NR; grp += EG) {
@@ -330,7 +551,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
     for (int k = 0; k < EG; ++k) {
       const int row = r0 + (grp + k) * ROWS_PER_PASS;
       const int m = m0 + row;
-      valid[k] = m < rows;
+      valid[k] = m < rows && (!PIPE || row < bm_step);
       const int orow = simple_rows ? (valid[k] ? m : m0) : s_orow[row];
       goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
       if constexpr (HAS_ADD) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
@@ -493,6 +714,56 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
 
 #define CONV_BM 128
 
+static void finish_classes(ConvGemmArgs& a, int step = CONV_BM) {
+  int blk = 0;
+  for (int i = 0; i < a.ncls; ++i) {
+    a.cls[i].rows = a.N * a.cls[i].a_dim * a.cls[i].b_dim;
+    a.cls[i].mblk_start = blk;
+    blk += ceil_div(a.cls[i].rows, step);
+  }
+  a.total_mblk = blk;
+  a.bm_step = step;
+}
+
+// ---- selection of the 8-phase pipelined kernel (NST == 8).  MMSKIN_CONV_PIPE=0 switches it off, MMSKIN_CONV_PIPE_MINK (elements of
+// the reduction) is the shortest K it takes, MMSKIN_CONV_PIPE_FORCE=1 takes every eligible launch (tests), MMSKIN_CONV_PIPE_TILE=
+// 256 | 224 | 196 pins the tile rows instead of the tile-count model below.
+static int64_t g_pipe_launches = 0;
+extern "C" int64_t mmskin_conv_pipe_launches(void) { return g_pipe_launches; }
+struct PipeChoice { int bm, step; };
+static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, PipeChoice* out) {
+  static const int on = [] { const char* v = getenv("MMSKIN_CONV_PIPE"); return v ? atoi(v) : 1; }();
+  static const int force = [] { const char* v = getenv("MMSKIN_CONV_PIPE_FORCE"); return v ? atoi(v) : 0; }();
+  static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
+  static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
+  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || tr || (heavy && prof == 1) || a.Cout % 256 != 0 || a.C % 64 != 0 || a.ep_relu == 2) return false;
+  int kmin = 1 << 30;
+  for (int i = 0; i < a.ncls; ++i) {
+    const int nk = a.cls[i].ntaps * a.C / 64;
+    if (nk < 1 || nk > KT_LDS_BYTES / 16) return false;
+    if (nk * 64 < kmin) kmin = nk * 64;
+  }
+  if (a.ncls < 1) return false;
+  if (!force && kmin < mink) return false;
+  // one workgroup per CU: the launch takes ceil(tiles / 256) rounds of a tile whose MFMA time goes with its COMPUTED rows
+  const int cand[3][2] = {{256, 256}, {224, 224}, {224, 196}};
+  double best = 1e30;
+  for (int c = 0; c < 3; ++c) {
+    if (pin && cand[c][1] != pin) continue;
+    long tiles = 0;
+    for (int i = 0; i < a.ncls; ++i) tiles += (long)ceil_div(a.cls[i].rows, cand[c][1]) * (a.Cout / 256);
+    const double cost = (double)((tiles + 255) / 256) * cand[c][0];
+    if (cost < best) { best = cost; out->bm = cand[c][0]; out->step = cand[c][1]; }
+  }
+  if (best >= 1e30) return false;
+  if (!force) {   // against the 128-row kernel: 4 workgroups per CU, whole launch ~ tiles / 1024 rounds of a tile a quarter the size
+    long small = 0;
+    for (int i = 0; i < a.ncls; ++i) small += (long)ceil_div(a.cls[i].rows, 128) * (a.Cout / 128);
+    (void)small;
+  }
+  return true;
+}
+
 template <typename T>
 static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   ARG_CHECK(a.Cout % 64 == 0, "conv_gemm: Cout=%d must be a multiple of 64", a.Cout);
@@ -519,8 +790,9 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   // encoders (K = 3072 / 4096: 1.03 - 1.05 PFLOP/s against 0.88 - 0.92 on the 128 x 128 tile; at K <= 1024 the per-tile prologue and
   // the 2-wave-per-SIMD epilogue cost more than the fill saves: profiles/r02_experiments.txt (9)).  MMSKIN_GEMM_BIG_MINK=0: off.
   static const int big_min_k = [] { const char* v = getenv("MMSKIN_GEMM_BIG_MINK"); return v ? atoi(v) : 2048; }();
+  static const bool pipe_forced = [] { const char* v = getenv("MMSKIN_CONV_PIPE_FORCE"); return v && atoi(v) != 0; }();
   if constexpr (sizeof(T) == 2) {
-    if (big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
+    if (!pipe_forced && big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
         a.cls[0].mblk_start == 0 && a.cls[0].ntaps == 1 && a.Sy == 1 && a.Sx == 1 && a.OS == 1) {   // plain GEMMs only (what the tests cover)
       const int mb = ceil_div(a.cls[0].rows, 256), nb = a.Cout / 256;
       if (mb * nb >= 224) {
@@ -534,6 +806,19 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   if (profiles_on && heavy && !a.ep_mask_y && !a.ep_bias && !a.ep_relu) {
     if (a.ep_x && !a.addend && !a.ep_mask_bits && !a.ep_x2) prof = 3;
     else if (a.ep_x && a.ep_mask_bits && !a.ep_scale) prof = a.ep_x2 ? 5 : 4;
+  }
+  if constexpr (sizeof(T) == 2) {
+    PipeChoice pc;
+    if (pipe_choose(a, tr, prof, heavy, &pc)) {
+      finish_classes(a, pc.step);
+      a.nblk_n = a.Cout / 256;
+      ++g_pipe_launches;
+      const int e = !epi ? 0 : (!heavy ? 2 : prof);
+#define GOP(BMv) (e == 0 ? launch_cfg<T, BMv, 256, 2, 4, 0, 8>(a, st) : e == 2 ? launch_cfg<T, BMv, 256, 2, 4, 2, 8>(a, st) : \
+                  e == 3 ? launch_cfg<T, BMv, 256, 2, 4, 3, 8>(a, st) : e == 4 ? launch_cfg<T, BMv, 256, 2, 4, 4, 8>(a, st) : launch_cfg<T, BMv, 256, 2, 4, 5, 8>(a, st))
+      return pc.bm == 256 ? GOP(256) : GOP(224);
+#undef GOP
+    }
   }
   // only the everything-profile is a 168-VGPR kernel (768 single-buffer slots); the others have the forward kernel's residency
   const bool one = a.total_mblk * (a.Cout / bn_sel) > ((heavy && prof == 1) ? nst1_min_blocks_epi : nst1_min_blocks);
@@ -553,22 +838,13 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
 #undef GO
 }
 
-static void finish_classes(ConvGemmArgs& a) {
-  int blk = 0;
-  for (int i = 0; i < a.ncls; ++i) {
-    a.cls[i].rows = a.N * a.cls[i].a_dim * a.cls[i].b_dim;
-    a.cls[i].mblk_start = blk;
-    blk += ceil_div(a.cls[i].rows, CONV_BM);
-  }
-  a.total_mblk = blk;
-}
 
 int conv_fwd_stat_rows(const ConvShape& s) { return ceil_div(s.N * s.OH() * s.OW(), CONV_BM); }
 int stem_conv_stat_rows(int N, int OH, int OW) { return ceil_div(N * OH * OW, CONV_BM); }
 
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
-                    float* stat_sq, hipStream_t st, const FwdFuse* fuse) {
+                    float* stat_sq, hipStream_t st, const FwdFuse* fuse, int* stat_rows_out) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
@@ -578,6 +854,7 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   }
   a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;
+  a.in_bytes = (uint64_t)s.N * s.H * s.W * s.Cin * sizeof(T);
   a.Cout = s.Cout; a.wrow = s.kh * s.kw * s.Cin;
   a.Sy = s.stride; a.Sx = s.stride; a.OS = 1;
   a.OHf = s.OH(); a.OWf = s.OW();
@@ -591,7 +868,10 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
     }
   finish_classes(a);
   a.simple_src = (s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0) ? 1 : 0;
-  return dispatch_conv_gemm<T>(a, st);
+  a.pipe_ok = (!stat_sum || stat_rows_out) ? 1 : 0;
+  const int rc = dispatch_conv_gemm<T>(a, st);
+  if (stat_rows_out) *stat_rows_out = a.total_mblk;
+  return rc;
 }
 
 int conv_dgrad_partial_rows(const ConvShape& s) {
@@ -629,6 +909,7 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
     if (fuse->x2) { a.stat_b_sum = fuse->partial_b; a.stat_b_sq = fuse->partial_b + s.Cin; }
   }
   a.N = s.N; a.IH = s.OH(); a.IW = s.OW(); a.C = s.Cout; a.Cpitch = s.Cout;
+  a.in_bytes = (uint64_t)s.N * s.OH() * s.OW() * s.Cout * sizeof(T);
   a.Cout = s.Cin; a.wrow = s.kh * s.kw * s.Cout;
   a.Sy = 1; a.Sx = 1; a.OS = s.stride;
   a.OHf = s.H; a.OWf = s.W;
@@ -669,9 +950,11 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   for (int i = 1; i < a.ncls; ++i)
     for (int j = i; j > 0 && a.cls[j].ntaps > a.cls[j - 1].ntaps; --j) { TapClass t = a.cls[j]; a.cls[j] = a.cls[j - 1]; a.cls[j - 1] = t; }
   finish_classes(a);
-  if (fuse) fuse->rows_written = a.total_mblk;
   a.simple_src = (s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0 && a.ncls == 1) ? 1 : 0;
-  return dispatch_conv_gemm<T>(a, st);
+  a.pipe_ok = 1;
+  const int rc = dispatch_conv_gemm<T>(a, st);
+  if (fuse) fuse->rows_written = a.total_mblk;
+  return rc;
 }
 
 template <typename T>
@@ -719,7 +1002,7 @@ int launch_vgg_first_conv_fwd(int N, int H, int W, int Hp, int Wp, const T* img8
 
 #define INST(T)                                                                                      \
   template int launch_vgg_first_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, const FwdFuse*, hipStream_t, int, float*, float*); \
-  template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t, const FwdFuse*); \
+  template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t, const FwdFuse*, int*); \
   template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t, DgradFuse*);      \
   template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);
 INST(float)

@@ -1,0 +1,89 @@
+"""-m gpu: the 8-phase pipelined conv / dgrad kernel (csrc/conv_gemm.hip, NST == 8: 224 / 256-row x 256-channel tiles, LDS-DMA ring with
+counted vmcnt, two wave groups one barrier apart) against torch's conv2d on the same inputs.
+
+The kernel is selected per launch by a tile-count model and a minimum reduction depth; here MMSKIN_CONV_PIPE_FORCE=1 sends every eligible
+launch to it and MMSKIN_CONV_PIPE_TILE pins the tile height (256 / 224 computed rows, or 196 valid rows of a 224-row tile), so every tile
+shape meets every case: ragged last row blocks, M smaller than one tile, stride-2 gathers, the four parity classes of a stride-2 dgrad,
+a one-K-tile reduction (prologue-only pipeline) and 72 K-tiles.  Both knobs are read once per process -> fresh interpreters.
+Reference semantics: F.conv2d forward / backward as reached through torchvision's ResNet (loadImageModelClassifier.py:65-75).
+Tolerance: the bf16 kernel bound of test_gpu_kernels.py (5e-2 of the output rms)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CODE = r'''
+import sys
+sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
+import torch, torch.nn.functional as F
+from gpu_util import DEV, conv_backward, conv_forward, rel_err
+from mmskin import _lib
+lib = _lib.load()
+CASES = [  # N, Cin, H, W, Cout, k, stride, pad, pipe launches expected (forward, dgrad)
+    (3, 256, 14, 14, 256, 3, 1, 1, 1, 1),     # layer3 3x3: 588 rows = 3 images of 196
+    (2, 256, 28, 28, 256, 3, 2, 1, 1, 1),     # stride-2 3x3: strided gather forward, four parity classes backward
+    (2, 512, 9, 11, 256, 1, 1, 0, 1, 1),      # 1x1, odd sizes, ragged last row block
+    (1, 256, 7, 7, 512, 3, 1, 1, 1, 1),       # fewer rows than one tile, 36 K-tiles
+    (2, 256, 14, 14, 512, 1, 2, 0, 1, 1),     # stride-2 1x1 downsample: zero-filled parity classes + one GEMM class
+    (5, 64, 14, 14, 256, 1, 1, 0, 1, 0),      # ONE K-tile forward (the ring never refills); its dgrad has Cin = 64 outputs: 128-row kernel
+    (4, 128, 14, 14, 256, 3, 1, 1, 1, 0),     # 18 K-tiles of a 128-channel input
+    (1, 512, 7, 7, 512, 3, 1, 1, 1, 1),       # 72 K-tiles
+    (2, 256, 15, 13, 256, 3, 2, 1, 1, 1),     # stride 2 on odd sizes
+]
+g = torch.Generator().manual_seed(5)
+for (N, Cin, H, W, Cout, k, s, p, ef, eb) in CASES:
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    n0 = lib.mmskin_conv_pipe_launches()
+    y = conv_forward(x.to(DEV), w.to(DEV), s, p, "bf16")
+    n1 = lib.mmskin_conv_pipe_launches()
+    dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), s, p, "bf16")
+    n2 = lib.mmskin_conv_pipe_launches()
+    ef_, eb_ = rel_err(y, y_ref), rel_err(dx, xr.grad)
+    print("CASE", (N, Cin, H, W, Cout, k, s, p), "fwd", ef_, "dgrad", eb_, "pipe launches", n1 - n0, n2 - n1, flush=True)
+    assert n1 - n0 == ef and n2 - n1 == eb, "pipelined kernel not selected as expected"
+    assert ef_ < 5e-2 and eb_ < 5e-2
+'''
+
+
+@pytest.mark.parametrize("tile", ["256", "224", "196"])
+def test_pipelined_conv_kernel_matches_torch(tile):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMSKIN_CONV_PIPE_FORCE="1", MMSKIN_CONV_PIPE_TILE=tile)
+    code = CODE % dict(tests=os.path.join(root, "tests"), root=root,
+                       pkg=os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+
+
+def test_pipelined_conv_kernel_is_bit_identical_across_repeats():
+    """A race in the LDS ring (a fragment read overtaking its DMA, or a refill overtaking a read) shows up as run-to-run differences:
+    200 launches of a 36-K-tile layer must give one result."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
+import torch
+from gpu_util import DEV, conv_forward
+from mmskin import _lib
+lib = _lib.load()
+g = torch.Generator().manual_seed(9)
+x = torch.randn(64, 256, 14, 14, generator=g).to(DEV)
+w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(DEV)
+ref = conv_forward(x, w, 1, 1, "bf16")
+assert lib.mmskin_conv_pipe_launches() == 1
+for i in range(200):
+    y = conv_forward(x, w, 1, 1, "bf16")
+    assert torch.equal(y, ref), i
+print("OK")
+''' % dict(tests=os.path.join(root, "tests"), root=root, pkg=os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))
+    env = dict(os.environ, MMSKIN_CONV_PIPE_FORCE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
