@@ -134,13 +134,35 @@ def self_launch(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))   # stderr of every rank is inherited
+    # poll EVERY child: a rank that dies during init or in a step would leave the others inside a collective until the RCCL
+    # timeout; terminate them at once and fail (rank 0's stdout is drained by a reader thread so a long line cannot block it)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     if any(codes):
-        raise SystemExit(f"bench.py: rank exit codes {codes}")
+        raise SystemExit(f"bench.py: rank exit codes {codes}" + (f" (rank {failed} failed first; the others were terminated)" if failed is not None else ""))
 
 
 def rehearse(args, rank, world):
@@ -321,6 +343,8 @@ def main():
         except ValueError:
             sync = None
 
+    reduced = [0]   # bytes all-reduced by this rank in the last step (diagnosis of the first multi-GPU lines)
+
     def step():
         if args.infer:
             return infer_step()
@@ -328,9 +352,9 @@ def main():
         loss = crit(model(image, meta), label)
         loss.backward()
         if sync is not None:
-            sync.finish()
+            reduced[0] = sync.finish()
         elif world > 1:
-            dp.allreduce_gradients(model, world)
+            reduced[0] = dp.allreduce_gradients(model, world)
         opt.step()
         return loss
 
@@ -347,10 +371,15 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
+        mine = dt
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        tmin = torch.tensor([mine], device=device, dtype=torch.float64)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_ms = {"min": round(float(tmin) / args.steps * 1e3, 3), "max": round(dt / args.steps * 1e3, 3)}
     loss_val = float(loss.detach())
 
     roofline, plan = None, None
@@ -388,17 +417,28 @@ def main():
         # per-launch HBM bytes from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, scripts/pmc_traffic.py); only
         # quoted when they were taken on exactly these kernel sources, else null
         traffic, traffic_note = None, "no PMC pass committed"
+        frac_production = mfma_busy = prod_us = None
         try:
             with open(os.path.join(ROOT, "profiles", "conv_gemm_traffic.json")) as f:
                 tj = json.load(f)
             if tj.get("source_hash") == source_hash():
                 traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "PMC pass on this build (profiles/conv_gemm_traffic.json)"
+                # the same launches in the PRODUCTION step (side stream on: they share HBM with the weight-gradient GEMMs), from
+                # the committed un-instrumented kernel trace of these sources; and the matrix-pipe busy share of the PMC pass
+                prod_us = (tj.get("production_trace") or {}).get("avg_launch_us")
+                if prod_us:
+                    frac_production = round(dom_fl / max(n_launch, 1) / (prod_us * 1e-6) / 1e12 / peak, 4)
+                mfma_busy = (tj.get("mfma_busy") or {}).get("mfma_busy_share")
             else:
                 traffic_note = f"committed PMC pass is for sources {tj.get('source_hash')}, this build is {source_hash()}"
         except OSError:
             pass
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    # frac = frac_isolated: this pass runs with the side stream off; frac_production: the same launches beside the
+                    # weight-gradient stream (committed trace of these sources, null when the sources differ)
+                    "frac_isolated": round(achieved / peak, 4), "frac_production": frac_production,
+                    "production_avg_launch_us": prod_us, "mfma_busy_share": mfma_busy,
                     "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n_launch),
                     "algorithmic_gbytes_per_launch": round(dom_by / max(n_launch, 1) / 1e9, 4),
                     "algorithmic_gbps": round(dom_by / (dom_ms * 1e-3) / 1e9, 1),
@@ -428,6 +468,10 @@ def main():
             "loss": round(loss_val, 4),
             "roofline": roofline,
         }
+        if world > 1:   # what a first multi-GPU line needs to be diagnosable: the spread over ranks and the exchange volume
+            out["dp"] = {"ms_per_step_over_ranks": rank_ms, "allreduce_bytes_per_step_per_rank": int(reduced[0]),
+                         "overlap": sync is not None, "grad_segments_in_flight": dp.max_inflight_segments() if sync is not None else 0,
+                         "backend": args.backend}
         if world == 1 and not args.no_cpu_baseline and not args.infer:
             try:
                 out["cpu_baseline"] = cpu_baseline(32, workload=args.workload)   # batches of 32, not 256: bounded sample

@@ -15,6 +15,7 @@
 // consecutive output channels of one pixel -> packed LDS-staged epilogue with full-line stores.
 // Optional epilogue: per-row-block BatchNorm partial sums (deterministic slab, no atomics), and an
 // addend tensor (residual / accumulation).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -111,6 +112,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   int pipe_min_toff = 0;   // PIPE: most negative tap offset of this class (elements)
   const bool simple_src = !PIPE && p.simple_src != 0;   // 1x1 / stride 1: no source-row table (in-kernel stamps: the prologue was a fifth of a short-K workgroup's life)
   if constexpr (PIPE) {
+    // tap offsets as three packed words each (scalar loads issued together; a rolled loop over the taps waited for two dependent
+    // scalar loads per tap and was a quarter of the 3.7 us prologue of a 3x3 tile)
+    static_assert(MMSKIN_MAX_TAPS == 12 && offsetof(TapClass, offy) % 4 == 0 && offsetof(TapClass, offx) % 4 == 0 && offsetof(TapClass, wtap) % 4 == 0, "packed tap words");
+    const uint32_t* oyw = reinterpret_cast<const uint32_t*>(p.cls[ci].offy);
+    const uint32_t* oxw = reinterpret_cast<const uint32_t*>(p.cls[ci].offx);
+    const uint32_t wy[3] = {oyw[0], oyw[1], oyw[2]}, wx[3] = {oxw[0], oxw[1], oxw[2]};
+#define TAP_Y(t) ((int)(int8_t)(wy[(t) >> 2] >> (8 * ((t) & 3))))
+#define TAP_X(t) ((int)(int8_t)(wx[(t) >> 2] >> (8 * ((t) & 3))))
     // [0][BM] source offset of the row's pixel (elements), [1][BM] bit t = tap t of this row lies inside the image
     if (tid < BM) {
       const int m = m0 + tid;
@@ -121,19 +130,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
         const int a = rem / b_dim, b = rem - a * b_dim;
         const int iy = a * p.Sy, ix = b * p.Sx;
         base = ((img * IH + iy) * IW + ix) * p.Cpitch;
-        for (int t = 0; t < ntaps; ++t) {
-          const int y = iy + p.cls[ci].offy[t], x = ix + p.cls[ci].offx[t];
-          mask |= ((unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW) ? (1u << t) : 0u;
+#pragma unroll
+        for (int t = 0; t < MMSKIN_MAX_TAPS; ++t) {
+          const int y = iy + TAP_Y(t), x = ix + TAP_X(t);
+          mask |= (t < ntaps && (unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW) ? (1u << t) : 0u;
         }
       }
       s_src[tid] = base; s_src[BM + tid] = (int)mask;
     }
     // one int4 per K-tile (C % 64 == 0: a K-tile never straddles two taps), in BYTES: gather offset above the most negative tap
     // offset (the buffer descriptor's base carries that one, so the scalar offset of the DMA is never negative), tap bit, weight-row offset
-    for (int t = 0; t < ntaps; ++t) {
-      const int toff = (p.cls[ci].offy[t] * IW + p.cls[ci].offx[t]) * p.Cpitch;
-      pipe_min_toff = toff < pipe_min_toff ? toff : pipe_min_toff;
+#pragma unroll
+    for (int t = 0; t < MMSKIN_MAX_TAPS; ++t) {
+      const int toff = (TAP_Y(t) * IW + TAP_X(t)) * p.Cpitch;
+      pipe_min_toff = (t < ntaps && toff < pipe_min_toff) ? toff : pipe_min_toff;
     }
+#undef TAP_Y
+#undef TAP_X
     int4* s_kt = reinterpret_cast<int4*>(smem + tap_lds_bytes<BM>());
     const int cpt = C / BK, nkt = ntaps * cpt;
     for (int kt = tid; kt < nkt; kt += NT) {
@@ -247,20 +260,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   } while (0)
 
   if constexpr (PIPE) {
-    // ---- 8-phase pipelined main loop (MI355X playbook: LDS-DMA ring with COUNTED vmcnt, raw s_barrier, two waves per SIMD in
-    // opposite roles).  Wave row 0 (waves 0-3) and wave row 1 (waves 4-7; wave w and w + 4 share a SIMD) run half a phase apart:
-    // while one group issues its 16-MFMA cluster the other reads fragments from LDS and issues the LDS-DMA of a unit that is needed
-    // 5 - 6 phases later.  A K-tile (64 deep) is four phases; its operands are four 16 KB units
-    //   A0 = fragment rows 0-3 of both wave rows   B0 = channels 0-31 of every wave column   (first read in phase 0)
-    //   B1 = channels 32-63                                                                  (phase 1)
-    //   A1 = fragment rows 4..FM-1                                                           (phase 2)
-    // in two stages (K-tile parity).  Unit sequence q = 4t + {A0,B0,B1,A1}; phase g = 4t + ph issues q = g + 6.  Fragments stay in
-    // registers across the phases that reuse them (A0: ph 0-1, B0: ph 0+3, B1: ph 1-2, A1: ph 2-3).
-    // The load side is kept to a few instructions per phase because its ISSUE time (not bandwidth) is what must fit under the other
-    // group's 256-cycle MFMA cluster: operands arrive through `buffer_load_dwordx4 ... offen lds` -- the per-lane part of the address
-    // is a loop-invariant 32-bit VGPR offset, the K-tile's offset is the instruction's SCALAR offset, and a row whose tap lies outside
-    // the image (or past the tile's valid rows) gets an out-of-range offset, for which the buffer unit writes zeros: no zero page, no
-    // 64-bit address arithmetic, three VALU instructions per gathered row and none for the weights.
+    // ---- pipelined main loop (MI355X: LDS-DMA ring with COUNTED vmcnt, raw s_barrier, two waves per SIMD).
+    // A K-tile (64 deep) is four phases of 16 MFMAs per wave (one quadrant of the wave's 16*FM x 64 output tile); its operands are four
+    // 16 KB units in one of two stages (K-tile parity):
+    //   A0 = fragment rows 0-3 of both wave rows     B0 = channels 0-31 of every wave column
+    //   A1 = fragment rows 4..FM-1                   B1 = channels 32-63
+    // Unit sequence q = 4t + {A0, B0, B1, A1}.  Every wave runs the same stream, software-pipelined one phase deep:
+    //   phase g:  MFMA cluster of quadrant g  ||  ds_read of unit g + 2's fragments (used by cluster g + 1 / g + 2)
+    //             ||  LDS-DMA issue of unit g + 6  ->  s_waitcnt vmcnt(6)  ->  s_barrier
+    // The fragment reads and the DMA sit BETWEEN the wave's own MFMAs (sched_group_barrier / sched_barrier pin that): an MFMA
+    // occupies the issue port for 8 of its 16 cycles and two waves share the pipe, so the ~25 non-MFMA instructions of a phase
+    // issue in the gaps instead of in front of the cluster (measured before this form: load-side issue time and MFMA time ADDED,
+    // 790 cycles per phase for 512 cycles of MFMA; profiles/r03_experiments.txt).
+    //   RAW: unit q is read in phase q - 2; the barrier in front of that phase follows every wave's wait of phase q - 3, which
+    //        leaves only units > (q - 3) + 3 in flight.
+    //   WAR: unit q + 8 (same region) is issued in phase q + 2, four phases after the reads, which were consumed (lgkmcnt) three
+    //        barriers earlier.
+    // Operands arrive through `buffer_load_dwordx4 ... offen lds`: the per-lane part of the address is a loop-invariant 32-bit
+    // VGPR offset, the K-tile's offset is the instruction's SCALAR offset, and a row whose tap lies outside the image (or past
+    // the tile's valid rows) gets an out-of-range offset, for which the buffer unit writes zeros: no zero page, no 64-bit address
+    // arithmetic, three VALU instructions per gathered row and none for the weights.
     static_assert(sizeof(T) == 2 && WAVES_M == 2 && WAVES_N == 4 && BN == 256 && FM >= 5 && FM <= 8, "PIPE tile");
     constexpr int STAGE = (256 + BN) * 128;
     constexpr uint32_t OOB = 0xF0000000u;   // >= any num_records the launcher admits
@@ -289,7 +308,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
     {
       const uint64_t ba = (uint64_t)(uintptr_t)in_b + (int64_t)pipe_min_toff * (int)sizeof(T);
       const uint64_t bb = (uint64_t)(uintptr_t)p.w + (uint64_t)n0 * p.wrow * sizeof(T);
-      srdA = srd_t{(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, (uint32_t)p.in_bytes - (uint32_t)(pipe_min_toff * (int)sizeof(T)), 0x00020000u};   // the range check covers voffset + soffset from the biased base
+      // the range check covers voffset + soffset from the (biased) base
+      srdA = srd_t{(uint32_t)ba, (uint32_t)(ba >> 32) & 0xffffu, (uint32_t)p.in_bytes - (uint32_t)(pipe_min_toff * (int)sizeof(T)), 0x00020000u};
       srdB = srd_t{(uint32_t)bb, (uint32_t)(bb >> 32) & 0xffffu, 0xE0000000u, 0x00020000u};
     }
     uint32_t s_zero;   // opaque scalar zero: scalar offsets handed to the DMA are SALU results (a VALU-written SGPR needs 5 wait states before a VMEM reads it)
@@ -322,105 +342,128 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   } while (0)
 #define BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define LDSQ(ptr) (*reinterpret_cast<const uint4*>(ptr))
     STAMP(1);
-    {   // prologue: units 0..5 = A0 B0 B1 A1 of K-tile 0, A0 B0 of K-tile 1
-      const int4 k0 = s_kt[0];
-      const uint32_t a0_ = RFL(k0.x), b0_ = RFL(k0.y), w0_ = RFL(k0.z);
-      ISSUE_A(0, a0_, b0_, 0) ISSUE_B(0, w0_, 0) ISSUE_B(1, w0_, 0) ISSUE_A(1, a0_, b0_, 0)
-      if (nk > 1) { const int4 k1p = s_kt[1]; const uint32_t a1_ = RFL(k1p.x), b1_ = RFL(k1p.y), w1_ = RFL(k1p.z); ISSUE_A(0, a1_, b1_, STAGE) ISSUE_B(0, w1_, STAGE) }
-      STAMP(2);
-      WAIT_VM(NQ - 3);   // A0, B0, B1 of K-tile 0 have landed
-      BAR();
-      STAMP(3);
-    }
-    // Synchronisation: ONE barrier per phase.  Wave row 0 runs  load(p) | barrier | mfma(p),  wave row 1  barrier | load(p) | mfma(p):
-    // between two barriers group 0 does mfma(p) + load(p+1) and group 1 load(p) + mfma(p), so each SIMD's matrix pipe alternates
-    // between its two waves without a second rendezvous (with load longer than the MFMA cluster the two-barrier form idles the pipe for
-    // the difference in EVERY half phase; this one only for what the two halves do not cover together).
-    //   RAW: group 0 reads unit q in phase need(q) <= q - 1, between barriers need-1 and need; group 1's last wait before that
-    //        barrier is the one of phase need - 2  ->  phase g waits until everything up to unit g + 3 has landed (3 units in flight).
-    //   WAR: a region is refilled >= 2 phases after its last fragment read; those reads have returned (lgkmcnt before the MFMAs
-    //        that consume them) before the reading group's next barrier, which precedes either group's refill.
-    const bool grp1 = wid_u >= 4;
     const int off0 = ((g) ^ sw) << 4, off1 = ((4 + g) ^ sw) << 4;
     const unsigned char* Ard = As + (wm * 128 + l15) * 128;              // A region: [wave row][128 rows]
     const unsigned char* Brd = As + 256 * 128 + (wn * 64 + l15) * 128;   // B region
-    uint4 fa[4][2], fb0[2][2], fb1[2][2];
+    uint4 fa0[4][2], fa1[4][2], fbx[2][2], fby[2][2];   // A0 / A1 fragments; the two B halves swap roles every K-tile
+    {   // prologue: both stages = units 0..7 = K-tiles 0 and 1
+      const int4 k0 = s_kt[0];
+      const uint32_t a0_ = RFL(k0.x), b0_ = RFL(k0.y), w0_ = RFL(k0.z);
+      ISSUE_A(0, a0_, b0_, 0) ISSUE_B(0, w0_, 0) ISSUE_B(1, w0_, 0) ISSUE_A(1, a0_, b0_, 0)
+      if (nk > 1) {
+        const int4 k1p = s_kt[1];
+        const uint32_t a1_ = RFL(k1p.x), b1_ = RFL(k1p.y), w1_ = RFL(k1p.z);
+        ISSUE_A(0, a1_, b1_, STAGE) ISSUE_B(0, w1_, STAGE) ISSUE_B(1, w1_, STAGE) ISSUE_A(1, a1_, b1_, STAGE)
+      }
+      STAMP(2);
+      WAIT_VM(NQ - 4);   // K-tile 0 has landed (phases 0 and 1 read its B1 / A1 before the loop's first barrier)
+      BAR();
+      STAMP(3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { fa0[j][0] = LDSQ(Ard + off0 + j * 2048); fa0[j][1] = LDSQ(Ard + off1 + j * 2048); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { fbx[i][0] = LDSQ(Brd + off0 + i * 2048); fbx[i][1] = LDSQ(Brd + off1 + i * 2048); }
 #ifdef MMSKIN_ABLATE
+      if (abl & 32) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fa[j][s] = make_uint4(0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+          for (int j = 0; j < 4; ++j) { fa0[j][s] = make_uint4(0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u); fa1[j][s] = fa0[j][s]; }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { fb0[i][s] = make_uint4(0x3c003c00u, 0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u); fb1[i][s] = fb0[i][s]; }
-    }
+          for (int i = 0; i < 2; ++i) { fbx[i][s] = make_uint4(0x3c003c00u, 0x3c003c00u + tid, 0x3c003c00u, 0x3c003c00u); fby[i][s] = fbx[i][s]; }
+        }
+      }
 #endif
-    uint32_t ka1, kb1, kw1;   // K-tile t + 1: gather offset, tap bit, weight offset (scalars)
-    { const int4 k1v = s_kt[nk > 1 ? 1 : 0]; ka1 = RFL(k1v.x); kb1 = RFL(k1v.y); kw1 = RFL(k1v.z); }
-#define LDSQ(ptr) (*reinterpret_cast<const uint4*>(ptr))
-#define MMA_BLOCK(FB, IB, NJ, JB)                                                        \
+    }
+    uint32_t ka2, kb2, kw2;   // K-tile t + 2: gather offset, tap bit, weight offset (scalars)
+    { const int4 k2i = s_kt[nk > 2 ? 2 : 0]; ka2 = RFL(k2i.x); kb2 = RFL(k2i.y); kw2 = RFL(k2i.z); }
+// the MFMAs of one k half of a quadrant; NRD fragment reads are spread between the first ones (INTERLEAVE), the unit's DMA follows
+#define MMA_HALF(FA, FB, IB, NJ, JB, S)                                                  \
   if (!(abl & 4)) {                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                       \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                        \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                      \
-        _Pragma("unroll") for (int j = 0; j < (NJ); ++j) Mma<T>::run(FB[i][s], fa[j][s], acc[(IB) + i][(JB) + j]); \
-    __builtin_amdgcn_s_setprio(0);                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                        \
+      _Pragma("unroll") for (int j = 0; j < (NJ); ++j) Mma<T>::run(FB[i][S], FA[j][S], acc[(IB) + i][(JB) + j]); \
   }
-// One K-tile = four phases.  STEADY = 1: every unit issued from these phases exists and three units stay in flight (no tail
-// arithmetic in the loop body).  (Unrolling by the stage parity made hipcc rename the accumulators between the two bodies:
-// 31 v_mov_b64 per K-tile and spills; the stage offset costs four v_add per K-tile instead.)
-#define PIPE_KTILE(STEADY)                                                                                              \
+#define INTERLEAVE(NRD, NMF)                                                             \
+  _Pragma("unroll") for (int q_ = 0; q_ < (NMF); ++q_) {                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+    if (q_ < (NRD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   \
+  }
+// Every second phase ends with the rendezvous: my DMA pieces up to unit g + 4 have landed (4 younger units stay in flight), my
+// fragment reads have returned (so the regions they came from may be refilled after the barrier), then the barrier.
+#define PHASE_SYNC(STEADY, REM)                                                          \
+  if (STEADY) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else { WAIT_VM(REM); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } \
+  BAR();
+// One K-tile = four phases; phase g = 4t + ph issues unit g + 8 (the same region two K-tiles later) and reads unit g + 2:
+//   ph0  mfma (A0, B0)   reads B1(t)   -> FBY      issues A0(t+2)
+//   ph1  mfma (A0, B1)   reads A1(t)   -> fa1      issues B0(t+2)      | sync
+//   ph2  mfma (A1, B1)   reads A0(t+1) -> fa0      issues B1(t+2)
+//   ph3  mfma (A1, B0)   reads B0(t+1) -> FBY      issues A1(t+2)      | sync   (FBY is dead after ph2: the next K-tile swaps the roles)
+// RAW: the reads of phases g + 1, g + 2 (units g + 3, g + 4) follow the sync of odd phase g, whose wait leaves only units > g + 4
+// in flight.  WAR: unit g + 8 overwrites unit g, read in phase g - 2 and returned before the sync that ends phase g - 2 or g - 1.
+// STEADY = 1: K-tile t + 2 exists (all four units are issued, four stay in flight).
+#define PIPE_KTILE(STEADY, FBX, FBY)                                                                                    \
   {                                                                                                                     \
     const int sel = (t & 1) * STAGE, seln = STAGE - sel;                                                                \
     const int g4 = 4 * t;                                                                                               \
-    const int4 k2v = s_kt[(STEADY) || t + 2 < nk ? t + 2 : nk - 1];                                                     \
+    const int4 k3v = s_kt[(STEADY) || t + 3 < nk ? t + 3 : nk - 1];                                                     \
     const unsigned char* A0p = Ard + sel + off0; const unsigned char* A1p = Ard + sel + off1;                           \
     const unsigned char* B0p = Brd + sel + off0; const unsigned char* B1p = Brd + sel + off1;                           \
-    /* ---- phase 0: (A0, B0) */                                                                                        \
-    if (grp1) BAR();                                                                                                    \
-    if (!(abl & 32)) {                                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) { fb0[i][0] = LDSQ(B0p + i * 2048); fb0[i][1] = LDSQ(B1p + i * 2048); } \
-      __builtin_amdgcn_sched_barrier(0);                                                                                \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) { fa[j][0] = LDSQ(A0p + j * 2048); fa[j][1] = LDSQ(A1p + j * 2048); } \
-    }                                                                                                                   \
-    if ((STEADY) || t + 1 < nk) { ISSUE_B(1, kw1, seln) }                                                               \
-    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 4 - g4);                                                                  \
-    if (!grp1) BAR();                                                                                                   \
-    MMA_BLOCK(fb0, 0, 4, 0)                                                                                             \
-    /* ---- phase 1: (A0, B1) */                                                                                        \
-    if (grp1) BAR();                                                                                                    \
-    const uint32_t ka2 = RFL(k2v.x), kb2 = RFL(k2v.y), kw2 = RFL(k2v.z);                                                \
-    if (!(abl & 32)) {                                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) { fb1[i][0] = LDSQ(B0p + (2 + i) * 2048); fb1[i][1] = LDSQ(B1p + (2 + i) * 2048); } \
-    }                                                                                                                   \
-    if ((STEADY) || t + 1 < nk) { ISSUE_A(1, ka1, kb1, seln) }                                                          \
-    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 5 - g4);                                                                  \
-    if (!grp1) BAR();                                                                                                   \
-    MMA_BLOCK(fb1, 2, 4, 0)                                                                                             \
-    /* ---- phase 2: (A1, B1) */                                                                                        \
-    if (grp1) BAR();                                                                                                    \
-    if (!(abl & 32)) {                                                                                                  \
-      _Pragma("unroll") for (int j = 0; j < FM - 4; ++j) { fa[j][0] = LDSQ(A0p + (4 + j) * 2048); fa[j][1] = LDSQ(A1p + (4 + j) * 2048); } \
-    }                                                                                                                   \
-    if ((STEADY) || t + 2 < nk) { ISSUE_A(0, ka2, kb2, sel) }                                                           \
-    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 6 - g4);                                                                  \
-    if (!grp1) BAR();                                                                                                   \
-    MMA_BLOCK(fb1, 2, FM - 4, 4)                                                                                        \
-    /* ---- phase 3: (A1, B0) */                                                                                        \
-    if (grp1) BAR();                                                                                                    \
-    if ((STEADY) || t + 2 < nk) { ISSUE_B(0, kw2, sel) }                                                                \
-    if (STEADY) WAIT_VM(3); else WAIT_VM(NQ - 7 - g4);                                                                  \
-    if (!grp1) BAR();                                                                                                   \
-    MMA_BLOCK(fb0, 0, FM - 4, 4)                                                                                        \
-    ka1 = ka2; kb1 = kb2; kw1 = kw2;                                                                                    \
+    const unsigned char* A0n = Ard + seln + off0; const unsigned char* A1n = Ard + seln + off1;                         \
+    const unsigned char* B0n = Brd + seln + off0; const unsigned char* B1n = Brd + seln + off1;                         \
+    const bool more = (STEADY) || t + 1 < nk, more2 = (STEADY) || t + 2 < nk;                                           \
+    /* ---- phase 0 */                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (!(abl & 32)) { _Pragma("unroll") for (int i = 0; i < 2; ++i) { FBY[i][0] = LDSQ(B0p + (2 + i) * 2048); FBY[i][1] = LDSQ(B1p + (2 + i) * 2048); } } \
+    MMA_HALF(fa0, FBX, 0, 4, 0, 0)                                                                                      \
+    INTERLEAVE(4, 8)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (more2) { ISSUE_A(0, ka2, kb2, sel) }                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    MMA_HALF(fa0, FBX, 0, 4, 0, 1)                                                                                      \
+    /* ---- phase 1 */                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    const uint32_t ka3 = RFL(k3v.x), kb3 = RFL(k3v.y), kw3 = RFL(k3v.z);                                                \
+    if (!(abl & 32)) { _Pragma("unroll") for (int j = 0; j < FM - 4; ++j) { fa1[j][0] = LDSQ(A0p + (4 + j) * 2048); fa1[j][1] = LDSQ(A1p + (4 + j) * 2048); } } \
+    MMA_HALF(fa0, FBY, 2, 4, 0, 0)                                                                                      \
+    INTERLEAVE(2 * (FM - 4), 8)                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (more2) { ISSUE_B(0, kw2, sel) }                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    MMA_HALF(fa0, FBY, 2, 4, 0, 1)                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    PHASE_SYNC(STEADY, NQ - 6 - g4)                                                                                     \
+    /* ---- phase 2 */                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (!(abl & 32) && more) { _Pragma("unroll") for (int j = 0; j < 4; ++j) { fa0[j][0] = LDSQ(A0n + j * 2048); fa0[j][1] = LDSQ(A1n + j * 2048); } } \
+    MMA_HALF(fa1, FBY, 2, FM - 4, 4, 0)                                                                                 \
+    INTERLEAVE(8, 2 * (FM - 4))                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (more2) { ISSUE_B(1, kw2, sel) }                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    MMA_HALF(fa1, FBY, 2, FM - 4, 4, 1)                                                                                 \
+    /* ---- phase 3 */                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (!(abl & 32) && more) { _Pragma("unroll") for (int i = 0; i < 2; ++i) { FBY[i][0] = LDSQ(B0n + i * 2048); FBY[i][1] = LDSQ(B1n + i * 2048); } } \
+    MMA_HALF(fa1, FBX, 0, FM - 4, 4, 0)                                                                                 \
+    INTERLEAVE(4, 2 * (FM - 4))                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    if (more2) { ISSUE_A(1, ka2, kb2, sel) }                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    MMA_HALF(fa1, FBX, 0, FM - 4, 4, 1)                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    PHASE_SYNC(STEADY, NQ - 8 - g4)                                                                                     \
+    ka2 = ka3; kb2 = kb3; kw2 = kw3;                                                                                    \
   }
     int t = 0;
-    for (; t + 2 < nk; ++t) PIPE_KTILE(1)
-    for (; t < nk; ++t) PIPE_KTILE(0)
-    BAR();   // every wave is done with the ring before it becomes the C staging buffer
+    for (; t + 3 < nk; t += 2) { PIPE_KTILE(1, fbx, fby) ++t; PIPE_KTILE(1, fby, fbx) --t; }
+    for (; t < nk; ++t) { PIPE_KTILE(0, fbx, fby) if (++t >= nk) break; PIPE_KTILE(0, fby, fbx) }
+#undef PHASE_SYNC
     STAMP(4);
 #undef PIPE_KTILE
-#undef MMA_BLOCK
+#undef INTERLEAVE
+#undef MMA_HALF
 #undef LDSQ
 #undef RFL
 #undef BAR
@@ -731,37 +774,40 @@ static void finish_classes(ConvGemmArgs& a, int step = CONV_BM) {
 static int64_t g_pipe_launches = 0;
 extern "C" int64_t mmskin_conv_pipe_launches(void) { return g_pipe_launches; }
 struct PipeChoice { int bm, step; };
+// Selection of the pipelined kernel (NST == 8).  One 512-thread workgroup per CU: it pays where the reduction is deep enough to
+// amortise a ~8 us prologue + epilogue that nothing overlaps (row-weighted K >= MMSKIN_CONV_PIPE_MINK, default 1024) and the launch
+// has enough tiles to cover most of the chip (>= MMSKIN_CONV_PIPE_MINTILES, default 192); measured per ResNet-50 layer in
+// profiles/r03_experiments.txt.  MMSKIN_CONV_PIPE=0 switches it off, MMSKIN_CONV_PIPE_FORCE=1 takes every eligible launch (tests),
+// MMSKIN_CONV_PIPE_TILE = 256 | 224 | 196 pins the tile rows instead of the tile-count model below.
 static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, PipeChoice* out) {
   static const int on = [] { const char* v = getenv("MMSKIN_CONV_PIPE"); return v ? atoi(v) : 1; }();
   static const int force = [] { const char* v = getenv("MMSKIN_CONV_PIPE_FORCE"); return v ? atoi(v) : 0; }();
   static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
+  static const int mintiles = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINTILES"); return v ? atoi(v) : 192; }();
   static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
-  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || tr || (heavy && prof == 1) || a.Cout % 256 != 0 || a.C % 64 != 0 || a.ep_relu == 2) return false;
-  int kmin = 1 << 30;
+  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || tr || (heavy && prof == 1) || a.Cout % 256 != 0 ||
+      a.C % 64 != 0 || a.ep_relu == 2 || a.ncls < 1)
+    return false;
+  double ksum = 0, rsum = 0;
   for (int i = 0; i < a.ncls; ++i) {
     const int nk = a.cls[i].ntaps * a.C / 64;
     if (nk < 1 || nk > KT_LDS_BYTES / 16) return false;
-    if (nk * 64 < kmin) kmin = nk * 64;
+    ksum += (double)a.cls[i].rows * nk * 64; rsum += a.cls[i].rows;
   }
-  if (a.ncls < 1) return false;
-  if (!force && kmin < mink) return false;
-  // one workgroup per CU: the launch takes ceil(tiles / 256) rounds of a tile whose MFMA time goes with its COMPUTED rows
+  if (rsum <= 0) return false;
+  // the launch takes ceil(tiles / 256) rounds of a tile whose MFMA time goes with its COMPUTED rows
   const int cand[3][2] = {{256, 256}, {224, 224}, {224, 196}};
   double best = 1e30;
+  long best_tiles = 0;
   for (int c = 0; c < 3; ++c) {
     if (pin && cand[c][1] != pin) continue;
     long tiles = 0;
     for (int i = 0; i < a.ncls; ++i) tiles += (long)ceil_div(a.cls[i].rows, cand[c][1]) * (a.Cout / 256);
     const double cost = (double)((tiles + 255) / 256) * cand[c][0];
-    if (cost < best) { best = cost; out->bm = cand[c][0]; out->step = cand[c][1]; }
+    if (cost < best) { best = cost; best_tiles = tiles; out->bm = cand[c][0]; out->step = cand[c][1]; }
   }
   if (best >= 1e30) return false;
-  if (!force) {   // against the 128-row kernel: 4 workgroups per CU, whole launch ~ tiles / 1024 rounds of a tile a quarter the size
-    long small = 0;
-    for (int i = 0; i < a.ncls; ++i) small += (long)ceil_div(a.cls[i].rows, 128) * (a.Cout / 128);
-    (void)small;
-  }
-  return true;
+  return force || (ksum / rsum >= mink && best_tiles >= mintiles);
 }
 
 template <typename T>

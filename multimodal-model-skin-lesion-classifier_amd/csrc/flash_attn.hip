@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   float m_run[4], l_run[4];
   f32x4_t oacc[DN];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { m_run[r] = -1e30f; l_run[r] = 0.f; }
+  for (int r = 0; r < 4; ++r) { m_run[r] = -3.4028235e38f; l_run[r] = 0.f; }
 #pragma unroll
   for (int i = 0; i < DN; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
           *reinterpret_cast<uint16_t*>(Ps + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(s[n][r]);
     } else {
     // ---- bias / masks; running max
-    float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+    float mx[4] = {-3.4028235e38f, -3.4028235e38f, -3.4028235e38f, -3.4028235e38f};   // -FLT_MAX, not -1e30: a row whose keys all carry the finite HF mask (finfo.min) must come out as the uniform average of V, as torch's softmax gives it
     bool ok[4][4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {

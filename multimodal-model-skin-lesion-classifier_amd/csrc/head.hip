@@ -15,16 +15,21 @@
 // Library-owned scratch for split reductions (split-K partial tiles, column-sum partial rows).  The head's
 // C entry points carry no workspace argument (they mirror nn.Linear / nn.LayerNorm call sites), so the
 // buffer is allocated lazily and only ever grows; every user runs on the caller's stream, in order.
-static float* head_scratch(size_t bytes) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (bytes > cap) {
-    if (buf) (void)hipFree(buf);   // implicit device sync: no kernel still reads the old buffer
+// One buffer PER DEVICE (the process model is one process per GPU, but nothing here may hand device 0's memory to a launch on
+// device 1); `slot` separates the regions two nested entry points use at the same time.
+static float* head_scratch(size_t bytes, int slot = 0) {
+  constexpr int MAXDEV = 16;
+  static float* buf[2][MAXDEV] = {};
+  static size_t cap[2][MAXDEV] = {};
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAXDEV) return nullptr;
+  if (bytes > cap[slot][d]) {
+    if (buf[slot][d]) (void)hipFree(buf[slot][d]);   // implicit device sync: no kernel still reads the old buffer
     size_t want = bytes < (size_t)(8 << 20) ? (size_t)(8 << 20) : bytes;
-    if (hipMalloc((void**)&buf, want) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
-    cap = want;
+    if (hipMalloc((void**)&buf[slot][d], want) != hipSuccess) { buf[slot][d] = nullptr; cap[slot][d] = 0; return nullptr; }
+    cap[slot][d] = want;
   }
-  return buf;
+  return buf[slot][d];
 }
 // out[i] = sum_s part[s*n + i]
 __global__ void split_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int64_t n) {
@@ -1148,12 +1153,8 @@ int mmskin_linear_forward_ex(const void* x, int x_dtype, const float* w, const f
   }
   const size_t xb = x_dtype == 1 ? align_up((size_t)M * K * 4, 256) : 0, yb = y_dtype == 1 ? align_up((size_t)M * N * 4, 256) : 0;
   // (the fp32 entry point may itself use head_scratch: keep these conversions in a region of their own behind it)
-  static float* side = nullptr; static size_t side_bytes = 0;
-  if (xb + yb > side_bytes) {
-    if (side) HIP_CHECK_RET(hipFree(side));
-    HIP_CHECK_RET(hipMalloc((void**)&side, xb + yb));
-    side_bytes = xb + yb;
-  }
+  float* side = head_scratch(xb + yb, 1);
+  if (!side) { mmskin_set_error("linear_forward_ex: scratch allocation failed"); return MMSKIN_ERR_HIP; }
   const float* xf = reinterpret_cast<const float*>(x);
   if (x_dtype == 1) {
     if ((rc = cvt_to_f32(reinterpret_cast<const bf16_t*>(x), side, (int64_t)M * K, st))) return rc;

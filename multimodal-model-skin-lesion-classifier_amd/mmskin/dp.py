@@ -22,10 +22,24 @@ import torch.distributed as dist
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 
+def max_inflight_segments():
+    """How many of the encoder's gradient segments may have their all-reduce queued behind backward at the same time
+    (MMSKIN_DP_STREAMS, default 2: layer4 + layer3 / the rest).  Every queued all-reduce is one more HBM consumer beside the main
+    chain and the weight-gradient stream (r01_e (8) / (13): a third concurrent consumer slows the main chain), and torch's
+    ProcessGroupNCCL runs them one after the other on its own stream anyway -- the wait streams only decide WHEN each may start."""
+    import os
+    return max(1, int(os.environ.get("MMSKIN_DP_STREAMS", "2")))
+
+
 def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s parameters and buffers."""
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src)
+    # broadcast into detach() views, not `.data`: a detached view shares the parameter's version counter, so caches keyed by it
+    # (ops.frozen_bf16: bf16 copies of frozen weights) see the write; a write through `.data` leaves the counter where it was
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.detach(), src)
+    from . import ops
+    ops.invalidate_frozen_cache()
 
 
 def _aliases(flat, grads):
@@ -113,12 +127,13 @@ class OverlappedGradSync:
         if not segs:
             return
         on_gpu = flat.is_cuda
-        while on_gpu and len(self._streams) < len(segs):
+        nstreams = min(len(segs), max_inflight_segments())
+        while on_gpu and len(self._streams) < nstreams:
             self._streams.append(torch.cuda.Stream(device=flat.device))
         for i, (off, numel) in enumerate(segs):
             view = flat[off:off + numel]
             if on_gpu:
-                s = self._streams[i]
+                s = self._streams[i % nstreams]       # segment i + nstreams queues behind segment i on the same wait stream
                 with torch.cuda.stream(s):
                     plan.wait_grad_segment(i, s)      # s waits for the segment's events only, not for the rest of backward
                     self._works.append(dist.all_reduce(view, group=self.group, async_op=True))

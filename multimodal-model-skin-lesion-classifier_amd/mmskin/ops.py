@@ -111,6 +111,12 @@ def frozen_bf16(*ws):
     return w16
 
 
+def invalidate_frozen_cache():
+    """Drop every cached bf16 weight copy.  Anything that rewrites parameters through `.data` (which does not move the version
+    counter) must call this; in-place ops on the parameter or a detach() view are seen by the version check on their own."""
+    _frozen_cache.clear()
+
+
 def lane_ok(x, N, K, fused_tail=False):
     """does mmskin_linear_lane take this shape?  (rows >= 2048, 64-multiple widths; 128-multiple N with a fused residual tail)"""
     M = x.numel() // x.shape[-1]
@@ -312,10 +318,9 @@ _dropout_counter = [0]
 def dropout(x, p, training):
     if not training or p <= 0.0:
         return x
-    # seed from torch's generator state so torch.manual_seed controls the masks
-    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-    _dropout_counter[0] += x.numel()
-    return DropoutFn.apply(x, p, seed, _dropout_counter[0])
+    # seed from torch's generator state so torch.manual_seed controls the masks; the call consumes counters [offset, offset + numel)
+    seed, offset = _dropout_state(p, x.numel())
+    return DropoutFn.apply(x, p, seed, offset)
 
 
 @no_second_order
@@ -443,7 +448,7 @@ def attention_packed(qkv, dropout_p=0.0, training=False, mask_add=None, bias=Non
     B, L, _, H, Dh = qkv.shape
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     if (qkv.is_cuda and qkv.dtype == torch.float32 and mask_add is None and bias is None and not causal and _rows_ok(L, Dh)
-            and not _flash_ok(q, k, v, mask_add, bias) and qkv.is_contiguous()):
+            and not _flash_ok(q, k, v, mask_add, bias, B * H) and qkv.is_contiguous()):
         p = dropout_p if training else 0.0
         seed, offset = _dropout_state(p, B * H * L * L)
         return AttentionPackedFn.apply(qkv, p, seed, offset)
@@ -520,17 +525,25 @@ def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
-def _flash_ok(q, k, v, mask_add, bias):
+def _flash_ok(q, k, v, mask_add, bias, bh):
     """The fused bf16 attention kernel (csrc/flash_attn.hip) serves bf16-operand mode whenever no gradient has to flow
     through the attention (frozen encoders -- the reference's default `frozen_weights` -- and inference); trainable blocks
     keep the unfused path, which saves the probabilities for its backward."""
-    return (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64) and q.is_cuda and q.shape == k.shape == v.shape
+    if not (get_linear_dtype() == "bf16" and q.shape[-1] in (32, 64) and q.is_cuda and q.shape == k.shape == v.shape
             and q.dtype == k.dtype == v.dtype and q.dtype in (torch.float32, torch.bfloat16)
-            and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v)))
+            and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v))):
+        return False
+    # the kernel's grid is (query tiles, batch * heads): batch * heads <= 65535 (flash_attn.hip ARG_CHECK); larger launches (DaViT
+    # window attention on >= 342 images: 64 windows x 3 heads each) take the rows / unfused path instead of raising.  q is
+    return bh <= 65535
 
 
 def _flash_forward(q, k, v, out, dims, strides, mask_add, bias, causal, p, seed, offset):
     B, H, L, Dh = dims
+    if bias is not None and tuple(bias.shape) != (H, L, L):
+        raise _lib.MMSkinError(f"mmskin.attention: bias must be [H, L, L] = {(H, L, L)}, got {tuple(bias.shape)}")
+    if mask_add is not None and tuple(mask_add.shape) != (B, L):
+        raise _lib.MMSkinError(f"mmskin.attention: mask_add must be [B, L] = {(B, L)}, got {tuple(mask_add.shape)}")
     st = (ctypes.c_int64 * 12)(*strides)
     m = _f32c(mask_add) if mask_add is not None else None
     bs = _f32c(bias) if bias is not None else None
@@ -543,8 +556,9 @@ def _flash_forward(q, k, v, out, dims, strides, mask_add, bias, causal, p, seed,
 def _dropout_state(p, n):
     if p <= 0.0:
         return 0, 0
+    off = _dropout_counter[0]          # this call consumes counters [off, off + n): ranges of successive calls never overlap
     _dropout_counter[0] += n
-    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _dropout_counter[0]
+    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, off
 
 
 def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
@@ -554,7 +568,7 @@ def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=N
     B, L, H, Dh = q.shape
     p = dropout_p if training else 0.0
     per16 = 16 // q.element_size()
-    if _flash_ok(q, k, v, mask_add, bias) and all(t.data_ptr() % 16 == 0 and all(s % per16 == 0 for s in t.stride()[:3])
+    if _flash_ok(q, k, v, mask_add, bias, B * H) and all(t.data_ptr() % 16 == 0 and all(s % per16 == 0 for s in t.stride()[:3])
                                                    for t in (q, k, v)):
         seed, offset = _dropout_state(p, B * H * L * L)
         out = torch.empty((B, L, H, Dh), device=q.device, dtype=q.dtype)
@@ -572,7 +586,7 @@ def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=N
 def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
-    if _flash_ok(q, k, v, mask_add, bias):
+    if _flash_ok(q, k, v, mask_add, bias, B * H):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         seed, offset = _dropout_state(p, B * H * L * L)
         out = torch.empty_like(q)
@@ -582,9 +596,7 @@ def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, 
         return _flash_forward(q, k, v, out, tuple(q.shape), strides, mask_add, bias, causal, p, seed, offset)
     seed = offset = 0
     if p > 0.0:
-        seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        _dropout_counter[0] += B * H * L * L
-        offset = _dropout_counter[0]
+        seed, offset = _dropout_state(p, B * H * L * L)
     # the one-workgroup-per-head kernel keeps L x L scores in LDS and walks the feature dimension serially: long sequences
     # and long feature dimensions (DaViT's channel attention: feature = tokens) go through the batched-GEMM path
     if mask_add is not None or bias is not None or causal or L * L * 4 > 64 * 1024 or q.shape[3] > 256:

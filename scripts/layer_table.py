@@ -1,36 +1,60 @@
-"""Map the conv_gemm dispatches of one bench step (rocprofv3 kernel trace) to ResNet-50 layers."""
+"""Per-layer table of the conv forward / dgrad / wgrad launches of ONE production training step (ResNet-50, batch 256, bf16) from a
+rocprofv3 kernel trace: microseconds, TFLOP/s, the HBM floor (algorithmic bytes / 6.3 TB/s), the MFMA floor (FLOP / 2.5 PFLOP/s) and
+the ratio to the larger floor.  Dispatch order is the plan's (csrc/backbone.hip); the side stream's launches are matched by kernel
+name.  usage: layer_table.py run_kernel_trace.csv"""
 import csv, sys
-def resnet50_units(N=256):
-    units=[("stem",dict(M=N*112*112,Cout=64,K=147))]
-    blocks=[]
-    cin,h=64,56
-    for li,(w,nb) in enumerate(zip((64,128,256,512),(3,4,6,3)),1):
+N = 256
+def resnet50():
+    blocks, cin, h = [], 64, 56
+    for li, (w, nb) in enumerate(zip((64, 128, 256, 512), (3, 4, 6, 3)), 1):
         for b in range(nb):
-            s=2 if (b==0 and li>1) else 1
-            ho=h//s
-            name=f"l{li}.{b}"
-            u=[(name+".c1",dict(M=N*h*h,Cout=w,K=cin,Min=N*h*h,Cin=cin)),
-               (name+".c2",dict(M=N*ho*ho,Cout=w,K=9*w,Min=N*h*h,Cin=w,s=s)),
-               (name+".c3",dict(M=N*ho*ho,Cout=4*w,K=w,Min=N*ho*ho,Cin=w))]
-            ds=None
-            if s!=1 or cin!=4*w: ds=(name+".ds",dict(M=N*ho*ho,Cout=4*w,K=cin,Min=N*h*h,Cin=cin,s=s))
-            blocks.append((u,ds)); cin=4*w; h=ho
-    return units,blocks
-units,blocks=resnet50_units()
-fwd=[units[0]]
-for u,ds in blocks:
+            s = 2 if (b == 0 and li > 1) else 1
+            ho = h // s
+            nm = f"l{li}.{b}"
+            u = [(nm + ".c1", dict(Mo=N * h * h, Mi=N * h * h, Cin=cin, Cout=w, taps=1)),
+                 (nm + ".c2", dict(Mo=N * ho * ho, Mi=N * h * h, Cin=w, Cout=w, taps=9)),
+                 (nm + ".c3", dict(Mo=N * ho * ho, Mi=N * ho * ho, Cin=w, Cout=4 * w, taps=1))]
+            ds = (nm + ".ds", dict(Mo=N * ho * ho, Mi=N * h * h, Cin=cin, Cout=4 * w, taps=1, s2=(s == 2))) if (s != 1 or cin != 4 * w) else None
+            blocks.append((u, ds)); cin = 4 * w; h = ho
+    return blocks
+blocks = resnet50()
+stem = ("stem", dict(Mo=N * 112 * 112, Mi=N * 224 * 224, Cin=3, Cout=64, taps=49))
+fwd = [stem]
+for u, ds in blocks:
     if ds: fwd.append(ds)
-    fwd+=u
-bwd=[]
-for u,ds in reversed(blocks):
-    for x in reversed(u): bwd.append(x)
-    if ds: bwd.append(ds)
-rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'conv_gemm_kernel' in r['Kernel_Name']][-105:]
-assert len(fwd)==53 and len(bwd)==52
-tot=0
-for (name,d),r in zip(fwd+bwd, rows):
-    us=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-    fl=2.0*d['M']*d['Cout']*d['K']
-    kind='F' if tot<53 else 'D'
-    tot+=1
-    print(f"{kind} {name:9s} M={d['M']:8d} N={d['Cout'] if kind=='F' else d.get('Cin',3):5d} K={d['K'] if kind=='F' else d['Cout']*(9 if 'c2' in name else 1):5d} {us:8.1f} us {fl/us/1e6:7.1f} TF/s  blocks={int(r['Grid_Size_X'])//256}")
+    fwd += u
+bwd = []   # per block, last to first: conv3, conv2, (downsample), conv1 -- the plan's dgrad order
+for u, ds in reversed(blocks):
+    bwd += [u[2], u[1]] + ([ds] if ds else []) + [u[0]]
+def flops(d): return 2.0 * d["Mo"] * d["Cout"] * d["Cin"] * d["taps"]
+def bytes_fwd(d):   # read the input once (a strided 1x1 reads a quarter of the pixels), the weights, write the output
+    mi = d["Mo"] if d.get("s2") else d["Mi"]
+    return 2.0 * (mi * d["Cin"] + d["Mo"] * d["Cout"] + d["Cout"] * d["Cin"] * d["taps"])
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+conv = [r for r in rows if "conv_gemm_kernel" in r["Kernel_Name"]]
+per_step = len(fwd) + len(bwd)
+conv = conv[-per_step:]
+def dur(r): return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+print(f"{'':2s}{'layer':10s} {'M':>8s} {'N':>5s} {'K':>5s} {'us':>8s} {'TF/s':>7s} {'HBM fl.':>8s} {'MFMA fl.':>8s} {'ratio':>6s}  kernel")
+tot = {"F": 0.0, "D": 0.0}
+for i, ((name, d), r) in enumerate(zip(fwd + bwd, conv)):
+    kind = "F" if i < len(fwd) else "D"
+    us = dur(r); tot[kind] += us
+    fl = flops(d); hb = bytes_fwd(d) / 6.3e12 * 1e6; mf = fl / 2.5e15 * 1e6
+    M, Nn, K = (d["Mo"], d["Cout"], d["Cin"] * d["taps"]) if kind == "F" else (d["Mi"], d["Cin"], d["Cout"] * d["taps"])
+    kn = "pipe 512 thr" if int(r["Workgroup_Size_X"]) == 512 else "128-row"
+    print(f"{kind} {name:10s} {M:8d} {Nn:5d} {K:5d} {us:8.1f} {fl / us / 1e6:7.0f} {hb:8.1f} {mf:8.1f} {us / max(hb, mf):6.2f}  {kn} x{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}")
+print(f"forward {tot['F'] / 1e3:.3f} ms, dgrad {tot['D'] / 1e3:.3f} ms per step (production: beside the side stream's weight-gradient GEMMs)")
+wg = [r for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]
+nw = 53
+wg = wg[-nw:]
+if len(wg) == nw:
+    order = [x for u, ds in reversed(blocks) for x in (list(reversed(u)) + ([ds] if ds else []))] + [stem]
+    # the plan enqueues a block's weight gradients as conv3, conv2, conv1 with the downsample one after conv1's
+    t = 0.0
+    for (name, d), r in zip(order, wg):
+        us = dur(r); t += us
+        fl = flops(d); hb = 2.0 * (d["Mi"] * d["Cin"] + d["Mo"] * d["Cout"]) / 6.3e12 * 1e6; mf = fl / 2.5e15 * 1e6
+        print(f"W {name:10s} {d['Cout']:8d} {d['Cin'] * d['taps']:5d} {d['Mo']:5d}".ljust(34) + f"{us:8.1f} {fl / us / 1e6:7.0f} {hb:8.1f} {mf:8.1f} {us / max(hb, mf):6.2f}  {r['Kernel_Name'][:40]}")
+    print(f"wgrad {t / 1e3:.3f} ms per step (GEMM launches only, side stream)")

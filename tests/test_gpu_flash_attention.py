@@ -87,6 +87,71 @@ def test_flash_forward_matches_unfused_and_torch(B, H, L, D, kind):
     assert rel_err(fused, want) < 6e-2, rel_err(fused, want)      # bf16 operands: max deviation 2-4 % of the output rms
 
 
+def test_flash_fully_masked_row_is_the_uniform_average_like_torch():
+    """A batch entry whose keys ALL carry the finite HuggingFace mask (finfo.min) -- torch's softmax gives the uniform average of V
+    there (every score is the same huge negative number); the fused kernel's running maximum starts at -FLT_MAX so that it does too,
+    and so does the unfused path (they used to disagree, the fused kernel wrote zeros)."""
+    B, H, L, D = 2, 2, 130, 64
+    q, k, v = _inputs(B, H, L, D, 21)
+    mask = torch.zeros(B, L)
+    mask[1, :] = torch.finfo(torch.float32).min
+    want = _torch_ref(q, k, v, mask)
+    assert rel_err(want[1], v[1].mean(1, keepdim=True).expand_as(want[1])) < 1e-5      # the reference IS the uniform average
+    dev = lambda t: t.to(DEV)
+    with torch.no_grad():
+        ops.set_linear_dtype("fp32")
+        unfused = ops.attention(dev(q), dev(k), dev(v), mask_add=dev(mask)).cpu()
+        ops.set_linear_dtype("bf16")
+        fused = ops.attention(dev(q), dev(k), dev(v), mask_add=dev(mask)).cpu()
+    assert rel_err(unfused, want) < 1e-4
+    assert rel_err(fused[1], want[1]) < 2e-2 and rel_err(fused[0], want[0]) < 6e-2
+
+
+def test_flash_grid_limit_falls_back_instead_of_raising():
+    """batch x heads > 65535 exceeds the fused kernel's grid (flash_attn.hip ARG_CHECK): the router must take the rows / unfused
+    path (DaViT stage-1 window attention on >= 342 images is 64 windows x 3 heads per image) and give the same numbers."""
+    B, H, L, D = 22000, 3, 16, 32
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, L, 3, H, D, generator=g)
+    want = _torch_ref(*(qkv[:8, :, i].permute(0, 2, 1, 3) for i in range(3))).permute(0, 2, 1, 3)
+    qd = qkv.to(DEV)
+    with torch.no_grad():
+        ops.set_linear_dtype("bf16")
+        assert not ops._flash_ok(qd[:, :, 0], qd[:, :, 1], qd[:, :, 2], None, None, B * H)
+        got = ops.attention_packed(qd)
+        small = ops.attention_packed(qd[:8].contiguous())       # 24 (batch, head) pairs: the fused kernel
+    assert got.shape == (B, L, H, D)
+    assert rel_err(got[:8].cpu(), want) < 1e-3                  # the fp32 rows kernel
+    assert rel_err(small.cpu(), want) < 6e-2
+
+
+def test_flash_rejects_a_misshapen_bias_or_mask():
+    q, k, v = (t.to(DEV) for t in _inputs(2, 2, 70, 64, 4))
+    ops.set_linear_dtype("bf16")
+    from mmskin import _lib
+    with torch.no_grad():
+        with pytest.raises(_lib.MMSkinError):
+            ops.attention(q, k, v, bias=torch.zeros(2, 70, 69, device=DEV))
+        with pytest.raises(_lib.MMSkinError):
+            ops.attention(q, k, v, mask_add=torch.zeros(3, 70, device=DEV))
+
+
+def test_dropout_counter_ranges_of_successive_calls_do_not_overlap():
+    """Call i consumes counters [c, c + n_i): a second, smaller call must not re-use a slice of the first one's range."""
+    ops._dropout_counter[0] = 500
+    torch.manual_seed(7)
+    s1, o1 = ops._dropout_state(0.1, 1000)
+    s2, o2 = ops._dropout_state(0.1, 10)
+    assert (o1, o2) == (500, 1500) and ops._dropout_counter[0] == 1510 and s1 == s2
+    x = torch.ones(4096, device=DEV)
+    ops._dropout_counter[0] = 0
+    a = ops.dropout(x, 0.5, True)
+    b = ops.dropout(x[:1024].contiguous(), 0.5, True)
+    ops._dropout_counter[0] = 4096
+    c = ops.dropout(x[:1024].contiguous(), 0.5, True)
+    assert torch.equal(b, c) and not torch.equal(b, a[:1024])    # the second call continues where the first one ended
+
+
 def test_flash_dropout_drops_the_same_elements_as_the_unfused_path():
     B, H, L, D = 2, 3, 200, 64
     q, k, v = (t.to(DEV) for t in _inputs(B, H, L, D, 9))
