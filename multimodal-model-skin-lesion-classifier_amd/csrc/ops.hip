@@ -157,27 +157,42 @@ static inline int reduce_groups(int nrows) {
 
 // partial-row counts up to this are reduced by the finalize kernel itself (one launch instead of two)
 #ifndef BN_SINGLE_STAGE_ROWS
-#define BN_SINGLE_STAGE_ROWS 64
+#define BN_SINGLE_STAGE_ROWS bn_single_stage_rows()
 #endif
+// MMSKIN_BN_SINGLE_ROWS (default 512): layers 3 - 4 of ResNet-50 at batch 256 leave 98 - 392 partial rows (64 - 256 with the
+// pipelined conv kernel's tiles) -- one 1024-thread finalize launch (16 row lanes x 2 chains) instead of pre-reduction + finalize
+static inline int bn_single_stage_rows() {
+  static const int v = [] { const char* e = getenv("MMSKIN_BN_SINGLE_ROWS"); return e ? atoi(e) : 512; }();
+  return v;
+}
 
 // ------------------------------------------------------------------ BN forward
-template <typename IN>
-__global__ void bn_finalize_kernel(const IN* __restrict__ ssum, const IN* __restrict__ ssq, int nrows,
+template <typename IN, int RL = 4>
+__global__ __launch_bounds__(64 * RL) void bn_finalize_kernel(const IN* __restrict__ ssum, const IN* __restrict__ ssq, int nrows,
                                    int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum,
                                    float* running_mean, float* running_var, float* scale, float* shift,
                                    float* save_mean, float* save_invstd) {
-  __shared__ double red[2][4][64];
+  __shared__ double red[2][RL][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int r = ry; r < nrows; r += 4) { s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c]; }
+  if (c < C) {
+    int r = ry;
+    double s1 = 0.0, q1 = 0.0;
+    for (; r + RL < nrows; r += 2 * RL) {     // two independent chains per lane
+      s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c];
+      s1 += (double)ssum[(size_t)(r + RL) * C + c]; q1 += (double)ssq[(size_t)(r + RL) * C + c];
+    }
+    if (r < nrows) { s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c]; }
+    s += s1; q += q1;
+  }
   red[0][ry][cx] = s; red[1][ry][cx] = q;
   __syncthreads();
   if (ry == 0 && c < C) {
-    s = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-    q = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) { s += red[0][i][cx]; q += red[1][i][cx]; }
     double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -206,6 +221,10 @@ int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, d
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch,
                        scratch + (size_t)G * C, G, C, count, gamma, beta, eps, momentum, running_mean, running_var,
                        scale, shift, save_mean, save_invstd);
+  } else if (nrows > 64) {   // up to BN_SINGLE_STAGE_ROWS partial rows in ONE launch: 16 row lanes x 2 chains each
+    hipLaunchKernelGGL((bn_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, stat_sum, stat_sq, nrows,
+                       C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
+                       save_invstd);
   } else {
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, stat_sum, stat_sq, nrows,
                        C, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean,
@@ -416,25 +435,33 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
   return MMSKIN_OK;
 }
 
-template <typename IN>
-__global__ void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
+template <typename IN, int RL = 4>
+__global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                        float* cA, float* cB, float* cC, int n_grad) {
-  __shared__ double red[2][4][64];
+  __shared__ double red[2][RL][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = ry; r < nrows; r += 4) {
+  if (c < C) {
+    int r = ry;
+    double t1 = 0.0, t2 = 0.0;
+    for (; r + RL < nrows; r += 2 * RL) {     // two independent chains per lane
       s1 += (double)partial[((size_t)r * 2) * C + c];
       s2 += (double)partial[((size_t)r * 2 + 1) * C + c];
+      t1 += (double)partial[((size_t)(r + RL) * 2) * C + c];
+      t2 += (double)partial[((size_t)(r + RL) * 2 + 1) * C + c];
     }
+    if (r < nrows) { s1 += (double)partial[((size_t)r * 2) * C + c]; s2 += (double)partial[((size_t)r * 2 + 1) * C + c]; }
+    s1 += t1; s2 += t2;
+  }
   red[0][ry][cx] = s1; red[1][ry][cx] = s2;
   __syncthreads();
   if (ry == 0 && c < C) {
-    s1 = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-    s2 = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) { s1 += red[0][i][cx]; s2 += red[1][i][cx]; }
     double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
     double dg = is * (s2 - mu * s1);   // sum dz * xhat
     if (dgamma && c < n_grad) dgamma[c] = (float)dg;
@@ -455,6 +482,9 @@ int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const 
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
+  } else if (nrows > 64) {
+    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nrows, C, count,
                        gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
