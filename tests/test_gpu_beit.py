@@ -36,6 +36,44 @@ def test_beit_matches_oracle():
         assert err < 2e-3 * max(float(g.abs().max()), 1e-3 * scale), (k, err)
 
 
+def test_beit_bf16_operand_mode_gradients_vs_emulation():
+    """A 2-block BEiT with every block trainable in bf16-OPERAND mode, batch 12 (2 364 token rows: every Linear of the blocks and the
+    patch embedding take the bf16 GEMM kernels; trainable attention stays on the fp32 ops): per-parameter gradient distance /
+    cosine to the fp32 oracle, bounded by the CPU bf16-operand emulation of the oracle (tests/bf16_emulation.py)."""
+    from bf16_emulation import assert_grads_not_worse_than_emulation, bf16_operand_emulation, grad_distance_report
+    from mmskin import ops
+    from models.hip_beit import HipBeit
+    x = det_tensor("beit.xb", (12, 3, 224, 224))
+    w = det_tensor("beit.wb", (12, 64))
+
+    def run(m, dev):
+        m.train()
+        f = m(x.to(dev))
+        (f * w.to(dev)).sum().backward()
+        return f.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+    cpu = det_init_(OracleBeit("beitv2_tiny_test", init_values=0.5))
+    f_ref, g_ref = run(cpu, "cpu")
+    emu = det_init_(OracleBeit("beitv2_tiny_test", init_values=0.5))
+    with bf16_operand_emulation():
+        f_emu, g_emu = run(emu, "cpu")
+    hip = HipBeit("beitv2_tiny_test", init_values=0.5)
+    hip.load_state_dict(cpu.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    prev = ops.get_linear_dtype()
+    try:
+        ops.set_linear_dtype("bf16")
+        f_hip, g_hip = run(hip, DEV)
+    finally:
+        ops.set_linear_dtype(prev)
+    assert rel_err(f_emu, f_ref) > 1e-4
+    assert rel_err(f_hip, f_ref) <= 1.5 * rel_err(f_emu, f_ref) + 1e-3, (rel_err(f_hip, f_ref), rel_err(f_emu, f_ref))
+    rows = grad_distance_report(g_ref, g_hip, g_emu)
+    worst = max(rows.values(), key=lambda v: v[0])
+    print("beit bf16 operand mode: features", rel_err(f_hip, f_ref), "emu", rel_err(f_emu, f_ref), "worst grad (l2 hip, cos hip, l2 emu, cos emu)", worst)
+    assert_grads_not_worse_than_emulation(rows)
+
+
 def test_config5_wiring_beitv2_large_bert():
     """BASELINE configs[4]: beitv2_large + bert-base-uncased + the RG-ATT fusion string, one (small-batch) training step."""
     from models import multimodalIntraInterModal as M

@@ -38,6 +38,46 @@ def test_davit_matches_oracle():
     assert not bad, bad
 
 
+def test_davit_bf16_operand_mode_gradients_vs_emulation():
+    """BASELINE configs[3] is quoted in bf16 and every DaViT block is trainable there: the backward of the bf16-OPERAND mode needs a
+    quantitative check in that dtype.  Batch 4 @ 224^2 puts the Linears of stages 1 - 2 (12 544 / 3 136 token
+    rows) and the stage-2 patch embedding on the bf16 GEMM kernels.  Per parameter: relative L2 distance and cosine of the HIP
+    gradient to the fp32 oracle's, bounded by the CPU bf16-operand emulation of the oracle (tests/bf16_emulation.py: the same
+    operand roundings, torch's summation order) -- at most 1.5 x its distance (+2e-3), cosine no more than 0.02 below its."""
+    from bf16_emulation import assert_grads_not_worse_than_emulation, bf16_operand_emulation, grad_distance_report
+    from mmskin import ops
+    from models.hip_davit import HipDaVit
+    x = det_tensor("davit.xb", (4, 3, 224, 224))
+    w = det_tensor("davit.wb", (4, 768))
+
+    def run(m, dev):
+        m.train()
+        f = m(x.to(dev))
+        (f * w.to(dev)).sum().backward()
+        return f.detach().cpu(), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+
+    cpu = det_init_(OracleDaVit())
+    f_ref, g_ref = run(cpu, "cpu")
+    emu = det_init_(OracleDaVit())
+    with bf16_operand_emulation():
+        f_emu, g_emu = run(emu, "cpu")
+    hip = HipDaVit("davit_tiny.msft_in1k")
+    hip.load_state_dict(cpu.state_dict(), strict=True)
+    hip = hip.to(DEV)
+    prev = ops.get_linear_dtype()
+    try:
+        ops.set_linear_dtype("bf16")
+        f_hip, g_hip = run(hip, DEV)
+    finally:
+        ops.set_linear_dtype(prev)
+    assert rel_err(f_emu, f_ref) > 1e-4                       # the emulation really rounds something at this size
+    assert rel_err(f_hip, f_ref) <= 1.5 * rel_err(f_emu, f_ref) + 1e-3, (rel_err(f_hip, f_ref), rel_err(f_emu, f_ref))
+    rows = grad_distance_report(g_ref, g_hip, g_emu)
+    worst = max(rows.values(), key=lambda v: v[0])
+    print("davit bf16 operand mode: features", rel_err(f_hip, f_ref), "emu", rel_err(f_emu, f_ref), "worst grad (l2 hip, cos hip, l2 emu, cos emu)", worst)
+    assert_grads_not_worse_than_emulation(rows)
+
+
 def test_davit_odd_input_size_and_config4_wiring():
     """Window padding / crop at a size that is not a multiple of 7*32, and BASELINE configs[3] end to end."""
     from models import multimodalIntraInterModal as M

@@ -268,6 +268,33 @@ def test_bf16_train_step_parity_at_baseline_shape():
     assert_not_worse_than_emulation(r_hip, r_emu, slack=1.25)
 
 
+@pytest.mark.parametrize("gamma", [0.1, 0.5, 0.75])
+def test_bf16_train_logit_error_over_last_bn_gamma(gamma):
+    """Where between the conditioned point (gamma 0.25: 1.4e-3) and torchvision's default init (gamma 1: 3e-2) does the 1e-2 bf16
+    bound on the TRAIN-mode logits break?  The benchmarked configuration at B = 256 @ 224^2 with the last BatchNorm of every
+    residual block at gamma in {0.1, 0.5, 0.75} (0.25 and 1.0 are test_bf16_train_step_parity_at_baseline_shape); for each point
+    the HIP step, the fp32 CPU oracle and the CPU bf16-storage emulation of the same step go to parity_report.jsonl.  Asserted
+    at EVERY point: the HIP step is no further from the fp32 oracle than 1.25 x the emulation (train logits, loss, running
+    statistics, head gradients, per-stage gradient cosines), and it meets the north_star's 1e-2 wherever the emulation does
+    (VERDICT r02 item 6a).  Reference semantics: one optimisation step of train_pad_20.py:102-113."""
+    img, meta, lab = _baseline_batch(256)
+    cpu, hip = build_pair("bf16", **RESNET50_KW)
+    damp_residual_branches(cpu, gamma); damp_residual_branches(hip, gamma)
+    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
+    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+    r_hip = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    del hip, g_h
+    emu = det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu")))
+    damp_residual_branches(emu, gamma)
+    emu = bf16_storage_emulation(emu)
+    out_e, loss_e, g_e = _step(emu, _rb(img), meta, lab, "cpu")
+    r_emu = stage_report(out_c, loss_c, g_c, out_e, loss_e, g_e, cpu, emu)
+    report(test="bf16_b256_gamma_sweep", gamma=gamma, hip=r_hip, emu=r_emu)
+    assert_not_worse_than_emulation(r_hip, r_emu, slack=1.25)
+    if r_emu["err_train_logits"] <= 1e-2 / 1.25:       # the emulation is inside the bound with the slack to spare: so must the kernels be
+        assert r_hip["err_train_logits"] < 1e-2, (gamma, r_hip["err_train_logits"], r_emu["err_train_logits"])
+
+
 def test_fp32_train_step_parity_at_production_size():
     """fp32 compute at B = 64 @ 224^2: the code paths that only engage at production size (single-buffer conv variants for
     launches of > 640 / 800 workgroups, the two-stage slab reduction for > 32 splits, the wgrad split policy, the parity
