@@ -787,9 +787,10 @@ static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, Pi
   static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
   static const int mintiles = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINTILES"); return v ? atoi(v) : 192; }();
   static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
-  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || tr || (heavy && prof == 1) || a.Cout % 256 != 0 ||
-      a.C % 64 != 0 || a.ep_relu == 2 || a.ncls < 1)
+  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
+      a.C % 64 != 0 || a.ncls < 1)
     return false;
+  if (tr && (heavy || a.addend || a.stat_sum || !a.out_f32)) return false;   // the transformer-residual epilogue's own contract (checked below)
   double ksum = 0, rsum = 0;
   for (int i = 0; i < a.ncls; ++i) {
     const int nk = a.cls[i].ntaps * a.C / 64;
@@ -838,17 +839,6 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   // encoders (K = 3072 / 4096: 1.03 - 1.05 PFLOP/s against 0.88 - 0.92 on the 128 x 128 tile; at K <= 1024 the per-tile prologue and
   // the 2-wave-per-SIMD epilogue cost more than the fill saves: profiles/r02_experiments.txt (9)).  MMSKIN_GEMM_BIG_MINK=0: off.
   static const int big_min_k = [] { const char* v = getenv("MMSKIN_GEMM_BIG_MINK"); return v ? atoi(v) : 2048; }();
-  static const bool pipe_forced = [] { const char* v = getenv("MMSKIN_CONV_PIPE_FORCE"); return v && atoi(v) != 0; }();
-  if constexpr (sizeof(T) == 2) {
-    if (!pipe_forced && big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
-        a.cls[0].mblk_start == 0 && a.cls[0].ntaps == 1 && a.Sy == 1 && a.Sx == 1 && a.OS == 1) {   // plain GEMMs only (what the tests cover)
-      const int mb = ceil_div(a.cls[0].rows, 256), nb = a.Cout / 256;
-      if (mb * nb >= 224) {
-        a.total_mblk = mb; a.nblk_n = nb;
-        return !epi ? launch_cfg<T, 256, 256, 2, 4, 0, 2>(a, st) : (tr ? launch_cfg<T, 256, 256, 2, 4, 6, 2>(a, st) : launch_cfg<T, 256, 256, 2, 4, 2, 2>(a, st));
-      }
-    }
-  }
   static const bool profiles_on = [] { const char* v = getenv("MMSKIN_CONV_EPI_PROFILES"); return !v || atoi(v) != 0; }();
   int prof = 1;
   if (profiles_on && heavy && !a.ep_mask_y && !a.ep_bias && !a.ep_relu) {
@@ -861,11 +851,22 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
       finish_classes(a, pc.step);
       a.nblk_n = a.Cout / 256;
       ++g_pipe_launches;
-      const int e = !epi ? 0 : (!heavy ? 2 : prof);
+      const int e = tr ? 6 : (!epi ? 0 : (!heavy ? 2 : prof));
 #define GOP(BMv) (e == 0 ? launch_cfg<T, BMv, 256, 2, 4, 0, 8>(a, st) : e == 2 ? launch_cfg<T, BMv, 256, 2, 4, 2, 8>(a, st) : \
+                  e == 6 ? launch_cfg<T, BMv, 256, 2, 4, 6, 8>(a, st) : \
                   e == 3 ? launch_cfg<T, BMv, 256, 2, 4, 3, 8>(a, st) : e == 4 ? launch_cfg<T, BMv, 256, 2, 4, 4, 8>(a, st) : launch_cfg<T, BMv, 256, 2, 4, 5, 8>(a, st))
       return pc.bm == 256 ? GOP(256) : GOP(224);
 #undef GOP
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
+        a.cls[0].mblk_start == 0 && a.cls[0].ntaps == 1 && a.Sy == 1 && a.Sx == 1 && a.OS == 1) {   // plain GEMMs only (what the tests cover)
+      const int mb = ceil_div(a.cls[0].rows, 256), nb = a.Cout / 256;
+      if (mb * nb >= 224) {
+        a.total_mblk = mb; a.nblk_n = nb;
+        return !epi ? launch_cfg<T, 256, 256, 2, 4, 0, 2>(a, st) : (tr ? launch_cfg<T, 256, 256, 2, 4, 6, 2>(a, st) : launch_cfg<T, 256, 256, 2, 4, 2, 2>(a, st));
+      }
     }
   }
   // only the everything-profile is a 168-VGPR kernel (768 single-buffer slots); the others have the forward kernel's residency
