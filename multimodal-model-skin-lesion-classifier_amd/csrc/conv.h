@@ -146,6 +146,13 @@ template <typename T>
 int launch_vgg_first_conv_wgrad(int N, int H, int W, int Hp, int Wp, const T* dout, const T* img8, float* slab,
                                 float* dwv, hipStream_t st, int stride = 1);
 
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels at 56 x 56 (ResNet-50 layer1 conv2): all nine taps from one staged input window, weights
+// resident in LDS, one workgroup per image (conv3x3_c64.hip).  launch_conv_fwd / launch_conv_dgrad route to it when it takes the shape.
+bool conv3x3_c64_takes(const ConvShape& s, bool bf16);
+int launch_conv3x3_c64_fwd(const ConvShape& s, const bf16_t* in, const bf16_t* w_staged, bf16_t* out, float* stat_sum, float* stat_sq,
+                           int stat_stride, hipStream_t st);
+int launch_conv3x3_c64_dgrad(const ConvShape& s, const bf16_t* dout, const bf16_t* wt_staged, bf16_t* din, DgradFuse* fuse, hipStream_t st);
+
 size_t conv_wgrad_slab_bytes(const ConvShape& s);
 // dw: fp32 OIHW [Cout][Cin][kh][kw], reduced over the split slabs.  cout_valid / cin_valid (0 = all): when the
 // GEMM operands carry zero padding (s.Cout / s.Cin rounded up to 64), dw is the UNPADDED

@@ -895,6 +895,12 @@ template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
                     float* stat_sq, hipStream_t st, const FwdFuse* fuse, int* stat_rows_out) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_fwd: %dx%d kernel has too many taps", s.kh, s.kw);
+  if constexpr (sizeof(T) == 2) {
+    if (!fuse && (!stat_sum || stat_rows_out) && conv3x3_c64_takes(s, true)) {
+      if (stat_rows_out) *stat_rows_out = s.N;
+      return launch_conv3x3_c64_fwd(s, in, w_staged, out, stat_sum, stat_sq, s.Cout, st);
+    }
+  }
   ConvGemmArgs a = {};
   a.in = in; a.w = w_staged; a.out = out; a.addend = nullptr;
   if (fuse) {
@@ -946,6 +952,11 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
                       hipStream_t st, DgradFuse* fuse) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "conv_dgrad: too many taps");
   ARG_CHECK(s.stride == 1 || s.stride == 2, "conv_dgrad: stride %d unsupported", s.stride);
+  if constexpr (sizeof(T) == 2) {
+    const bool prof3 = fuse && fuse->x && fuse->scale && fuse->shift && !fuse->mask_y && !fuse->mask_bits && !fuse->x2 && fuse->x_pitch == 0 && fuse->partial;
+    if (!addend && (!fuse || prof3) && conv3x3_c64_takes(s, true))
+      return launch_conv3x3_c64_dgrad(s, dout, wt_staged, din, fuse, st);
+  }
   ConvGemmArgs a = {};
   a.in = dout; a.w = wt_staged; a.out = din; a.addend = addend;
   if (fuse) {
