@@ -215,6 +215,16 @@ int mmskin_token_mean_backward(const float* dout, float* dx, int B, int L, int E
 int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, const float* mask_add, const float* bias,
                                    void* o, float* lse, int B, int H, int L, int Dh, const int64_t* strides12, int io_dtype,
                                    float scale, int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+/* Backward of the fused attention for TRAINABLE transformer blocks in bf16-operand mode (csrc/flash_attn_bwd.hip): dq, dk, dv from
+ * q, k, v, o, d(o) and the forward's lse, the probabilities recomputed tile by tile (no [B, H, L, L] tensor is kept).  All tensors fp32;
+ * strides15 = element strides (batch, head, token) of q, k, v, o (= dout) and of dq / dk / dv (shared), last dims contiguous; bias
+ * [H][L][L] needs its transpose biasT [H][key][query] beside it; delta [B][H][L] is scratch; ds_out (optional) [B][H][L][L] receives
+ * dS = d loss / d(scaled, biased score) so the caller can sum the bias gradient over the batch; dropout regenerated from (seed, offset)
+ * exactly as the forward drew it.  Replaces autograd through timm / transformers attention (loadImageModelClassifier.py:117-131,170-181). */
+int mmskin_flash_attention_backward(const float* q, const float* k, const float* v, const float* o, const float* dout, const float* lse,
+                                    const float* mask_add, const float* bias, const float* biasT, float* delta, float* dq, float* dk,
+                                    float* dv, float* ds_out, int B, int H, int L, int Dh, const int64_t* strides15, float scale,
+                                    int causal, float drop_p, uint64_t seed, uint64_t offset, void* stream);
 /* Inference lane of the transformer encoders in bf16-operand mode (no gradient flows: frozen encoders, evaluation): activations pass
  * between layers as bf16, so no fp32 <-> bf16 conversion passes run.  linear_forward_ex: x [M][K] and y [M][N] are fp32
  * (dtype MMSKIN_F32) or bf16 (MMSKIN_BF16) independently; w [N][K], b [N] fp32; act 0 none / 1 ReLU / 2 exact GELU, fused into the GEMM

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "mmskin_linear_lane": (_i, [_P, _i, _P, _i, _P, _P, _P, _f, _u64, _u64, _P, _i, _i, _i, _i, _i, _P]),
     "mmskin_layernorm_forward_mixed": (_i, [_P] * 5 + [_i, _i, _f, _P]),
     "mmskin_flash_attention_forward": (_i, [_P] * 7 + [_i] * 4 + [_P, _i, _f, _i, _f, _u64, _u64, _P]),
+    "mmskin_flash_attention_backward": (_i, [_P] * 14 + [_i] * 4 + [_P, _f, _i, _f, _u64, _u64, _P]),
     "mmskin_set_linear_dtype": (_i, [_i]),
     "mmskin_get_linear_dtype": (_i, []),
     "mmskin_im2col_forward": (_i, [_P] + [_i] * 8 + [_P, _P]),

@@ -553,6 +553,60 @@ def _flash_forward(q, k, v, out, dims, strides, mask_add, bias, causal, p, seed,
     return out
 
 
+def _flash_train_ok(q, k, v, bias, bh):
+    """Trainable attention on the fused kernels (forward with the row log-sum-exp kept, backward recomputing the probabilities:
+    csrc/flash_attn_bwd.hip) -- bf16-operand mode, gradients required, head dim 32 / 64, more than 64 tokens (shorter sequences have
+    the one-wave-per-head fp32 kernels).  MMSKIN_FLASH_BWD=0 keeps the unfused fp32 chain."""
+    import os
+    return (get_linear_dtype() == "bf16" and os.environ.get("MMSKIN_FLASH_BWD", "1") != "0" and q.is_cuda and q.shape[-1] in (32, 64)
+            and q.shape == k.shape == v.shape and q.shape[-2] > 64 and bh <= 65535 and _needs_grad(q, k, v, bias))
+
+
+@no_second_order
+class FlashAttnFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(Dh) + bias + mask) v with gradients, fused: q, k, v [B, H, L, Dh] fp32 (rounded to bf16 operands inside),
+    mask_add [B, L] or None, bias [H, L, L] or None (its gradient is the sum of dS over the batch), dropout on the probabilities."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask_add, bias, causal, p, seed, offset):
+        q, k, v = _f32c(q), _f32c(k), _f32c(v)
+        B, H, L, Dh = q.shape
+        out = torch.empty_like(q)
+        lse = torch.empty((B, H, L), device=q.device, dtype=torch.float32)
+        if bias is not None and tuple(bias.shape) != (H, L, L):
+            raise _lib.MMSkinError(f"mmskin.attention: bias must be [H, L, L] = {(H, L, L)}, got {tuple(bias.shape)}")
+        if mask_add is not None and tuple(mask_add.shape) != (B, L):
+            raise _lib.MMSkinError(f"mmskin.attention: mask_add must be [B, L] = {(B, L)}, got {tuple(mask_add.shape)}")
+        m = _f32c(mask_add) if mask_add is not None else None
+        bs = _f32c(bias) if bias is not None else None
+        st = (ctypes.c_int64 * 12)(*([q.stride(0), q.stride(1), q.stride(2)] * 4))
+        call("mmskin_flash_attention_forward", ptr(q), ptr(k), ptr(v), ptr(m) if m is not None else None, ptr(bs) if bs is not None else None,
+             ptr(out), ptr(lse), B, H, L, Dh, st, _lib.F32, 1.0 / Dh ** 0.5, int(causal), float(p), int(seed), int(offset), stream())
+        ctx.save_for_backward(q, k, v, out, lse, m, bs)
+        ctx.cfg = (bool(causal), float(p), int(seed), int(offset))
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, out, lse, m, bs = ctx.saved_tensors
+        causal, p, seed, offset = ctx.cfg
+        B, H, L, Dh = q.shape
+        dO = _f32c(dO)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        delta = torch.empty((B, H, L), device=q.device, dtype=torch.float32)
+        bT = bs.transpose(1, 2).contiguous() if bs is not None else None
+        ds = torch.empty((B, H, L, L), device=q.device, dtype=torch.float32) if bs is not None and ctx.needs_input_grad[4] else None
+        st = (ctypes.c_int64 * 15)(*([q.stride(0), q.stride(1), q.stride(2)] * 5))
+        call("mmskin_flash_attention_backward", ptr(q), ptr(k), ptr(v), ptr(out), ptr(dO), ptr(lse), ptr(m) if m is not None else None,
+             ptr(bs) if bs is not None else None, ptr(bT) if bT is not None else None, ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+             ptr(ds) if ds is not None else None, B, H, L, Dh, st, 1.0 / Dh ** 0.5, int(causal), p, seed, offset, stream())
+        dbias = None
+        if ds is not None:       # d(bias) = dS summed over the batch (deterministic column sum, as the unfused path does)
+            dbias = torch.empty((H, L, L), device=q.device, dtype=torch.float32)
+            call("mmskin_colsum", ptr(ds), ptr(dbias), B, H * L * L, stream())
+        return dq, dk, dv, None, dbias, None, None, None, None
+
+
 def _dropout_state(p, n):
     if p <= 0.0:
         return 0, 0
@@ -586,6 +640,9 @@ def attention_blhd(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=N
 def attention(q, k, v, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     B, H, L, _ = q.shape
     p = dropout_p if training else 0.0
+    if _flash_train_ok(q, k, v, bias, B * H):
+        seed, offset = _dropout_state(p, B * H * L * L)
+        return FlashAttnFn.apply(q, k, v, mask_add, bias, causal, p, seed, offset)
     if _flash_ok(q, k, v, mask_add, bias, B * H):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         seed, offset = _dropout_state(p, B * H * L * L)

@@ -172,6 +172,86 @@ def test_flash_dropout_drops_the_same_elements_as_the_unfused_path():
     assert rel_err(nodrop, outs["fp32"]) > 0.2
 
 
+def _attn_grads(fn, q, k, v, w, bias):
+    qs = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    bs = bias.clone().requires_grad_(True) if bias is not None else None
+    (fn(*qs, bs) * w).sum().backward()
+    return [t.grad.detach().double().cpu() for t in qs] + ([bs.grad.detach().double().cpu()] if bs is not None else [])
+
+
+@pytest.mark.parametrize("B,H,L,D,kind", [(2, 3, 197, 64, "bias"), (2, 2, 512, 64, "mask"), (1, 2, 130, 32, "causal"), (2, 2, 100, 64, "plain"),
+                                          (1, 2, 77, 32, "mask+causal+bias"), (1, 1, 65, 64, "plain")])
+def test_flash_backward_matches_fp64_autograd_and_the_unfused_path(B, H, L, D, kind, monkeypatch):
+    """Trainable attention in bf16-operand mode: forward with the row log-sum-exp kept + the recomputing backward (csrc/flash_attn_bwd.hip)
+    against (a) torch autograd through exact attention in fp64 -- bf16 operands: every gradient within 8e-2 of its rms at the worst
+    element and 2e-2 in relative L2 -- and (b) the unfused fp32 chain of this package (MMSKIN_FLASH_BWD=0), which is (a) to 1e-3.  Covers the relative
+    position bias and its gradient (BEiT: summed over the batch), key masks with -inf tails, the causal mask, ragged last tiles and a
+    sequence one token past the tile (65)."""
+    q, k, v = _inputs(B, H, L, D, 3 * L + D)
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(B, H, L, D, generator=g)
+    bias = torch.randn(H, L, L, generator=g) if "bias" in kind else None
+    mask = None
+    if "mask" in kind:
+        mask = torch.zeros(B, L)
+        mask[0, L // 2:] = -10000.0
+        mask[-1, L - 3:] = float("-inf")
+    causal = "causal" in kind
+    want = _attn_grads(lambda a, b_, c, bb: _torch_ref64(a, b_, c, mask, bb, causal), q.double(), k.double(), v.double(), w.double(),
+                       bias.double() if bias is not None else None)
+    dev = lambda t: None if t is None else t.to(DEV)
+    ops.set_linear_dtype("bf16")
+    fused = _attn_grads(lambda a, b_, c, bb: ops.attention(a, b_, c, mask_add=dev(mask), bias=bb, causal=causal), dev(q), dev(k), dev(v), dev(w), dev(bias))
+    monkeypatch.setenv("MMSKIN_FLASH_BWD", "0")
+    unfused = _attn_grads(lambda a, b_, c, bb: ops.attention(a, b_, c, mask_add=dev(mask), bias=bb, causal=causal), dev(q), dev(k), dev(v), dev(w), dev(bias))
+    for name, gf, gu, gw in zip(("dq", "dk", "dv", "dbias"), fused, unfused, want):
+        assert torch.isfinite(gf).all(), name
+        assert rel_err(gu, gw) < 2e-3, (name, "unfused", rel_err(gu, gw))
+        if name == "dbias":      # a sum of dS over the batch: heavy-tailed (a few elements are 10 - 30 x the rms), so the bf16-operand
+            # error is bounded against the largest element and in relative L2 instead of max-error / rms
+            assert float((gf - gw).abs().max()) < 2e-2 * float(gw.abs().max()), (name, float((gf - gw).abs().max()), float(gw.abs().max()))
+            assert float((gf - gw).norm() / gw.norm()) < 3e-2, (name, float((gf - gw).norm() / gw.norm()))
+        else:                    # two more bf16-rounded MFMA operands than the forward (dS and P^T): 8e-2 of the rms at the worst element
+            # (measured 4e-2 - 6.3e-2), relative L2 within 2e-2
+            assert rel_err(gf, gw) < 8e-2, (name, "fused", rel_err(gf, gw))
+            assert float((gf - gw).norm() / gw.norm()) < 2e-2, (name, float((gf - gw).norm() / gw.norm()))
+
+
+def _torch_ref64(q, k, v, mask_add, bias, causal):
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    if bias is not None:
+        s = s + bias[None]
+    if mask_add is not None:
+        s = s + mask_add.double()[:, None, None, :]
+    if causal:
+        L = q.shape[2]
+        s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool), 1), float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+def test_flash_backward_regenerates_the_forward_dropout_mask(monkeypatch):
+    """Dropout on the probabilities: the fused backward must rebuild exactly the mask the fused forward drew (counter-based generator on
+    the [B, H, L, L] element index) -- its gradients equal the unfused path's at the same generator position to bf16 accuracy, and a
+    different position gives different gradients."""
+    B, H, L, D = 2, 2, 200, 64
+    q, k, v = (t.to(DEV) for t in _inputs(B, H, L, D, 11))
+    w = torch.randn(B, H, L, D, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ops.set_linear_dtype("bf16")
+
+    def grads(pos):
+        torch.manual_seed(99)
+        ops._dropout_counter[0] = pos
+        return _attn_grads(lambda a, b_, c, bb: ops.attention(a, b_, c, 0.25, True), q, k, v, w, None)
+
+    fused = grads(4096)
+    other = grads(123456)
+    monkeypatch.setenv("MMSKIN_FLASH_BWD", "0")
+    unfused = grads(4096)
+    for name, gf, gu, go in zip(("dq", "dk", "dv"), fused, unfused, other):
+        assert rel_err(gf, gu) < 6e-2, (name, rel_err(gf, gu))
+        assert rel_err(go, gu) > 0.2, name
+
+
 def test_flash_reads_a_fused_qkv_tensor_in_place():
     """attention_blhd on slices of the [B, L, 3, H, Dh] output of a qkv Linear: no permute copies, token-major output."""
     B, L, H, D = 3, 197, 4, 64
