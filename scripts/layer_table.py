@@ -32,9 +32,32 @@ def bytes_fwd(d):   # read the input once (a strided 1x1 reads a quarter of the 
     return 2.0 * (mi * d["Cin"] + d["Mo"] * d["Cout"] + d["Cout"] * d["Cin"] * d["taps"])
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-conv = [r for r in rows if "conv_gemm_kernel" in r["Kernel_Name"]]
-per_step = len(fwd) + len(bwd)
-conv = conv[-per_step:]
+def is_conv(r): return "conv_gemm_kernel" in r["Kernel_Name"] or "conv3x3_c64_kernel" in r["Kernel_Name"]
+conv_all = [r for r in rows if is_conv(r)]
+# The forward downsample convolutions run on the side stream (another HSA queue) beside conv1..conv3 of their block, so start-time
+# order interleaves them arbitrarily: split the dispatches by queue -- the main queue carries stem, conv1..3 of every block and every
+# dgrad in plan order, the side queue the four forward downsample convolutions (and every weight-gradient GEMM).
+qkey = "Queue_Id" if "Queue_Id" in rows[0] else None
+if qkey:
+    counts = {}
+    for r in conv_all: counts[r[qkey]] = counts.get(r[qkey], 0) + 1
+    main_q = max(counts, key=counts.get)
+    main = [r for r in conv_all if r[qkey] == main_q]
+    side = [r for r in conv_all if r[qkey] != main_q]
+else:
+    main, side = conv_all, []
+fwd_main = [x for x in fwd if not x[0].endswith(".ds")]
+fwd_side = [x for x in fwd if x[0].endswith(".ds")]
+per_step_main = len(fwd_main) + len(bwd)
+if side and len(main) >= per_step_main and len(side) >= len(fwd_side):
+    order = fwd_main + bwd
+    conv = main[-per_step_main:]
+    side_last = side[-len(fwd_side):]
+    fwd = fwd_main + fwd_side
+    conv = conv[:len(fwd_main)] + side_last + conv[len(fwd_main):]
+else:
+    per_step = len(fwd) + len(bwd)
+    conv = conv_all[-per_step:]
 def dur(r): return (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 print(f"{'':2s}{'layer':10s} {'M':>8s} {'N':>5s} {'K':>5s} {'us':>8s} {'TF/s':>7s} {'HBM fl.':>8s} {'MFMA fl.':>8s} {'ratio':>6s}  kernel")
 tot = {"F": 0.0, "D": 0.0}
@@ -43,7 +66,7 @@ for i, ((name, d), r) in enumerate(zip(fwd + bwd, conv)):
     us = dur(r); tot[kind] += us
     fl = flops(d); hb = bytes_fwd(d) / 6.3e12 * 1e6; mf = fl / 2.5e15 * 1e6
     M, Nn, K = (d["Mo"], d["Cout"], d["Cin"] * d["taps"]) if kind == "F" else (d["Mi"], d["Cin"], d["Cout"] * d["taps"])
-    kn = "pipe 512 thr" if int(r["Workgroup_Size_X"]) == 512 else "128-row"
+    kn = "layer-1 3x3" if "conv3x3_c64" in r["Kernel_Name"] else ("pipelined" if int(r["Workgroup_Size_X"]) == 512 else "128-row")
     print(f"{kind} {name:10s} {M:8d} {Nn:5d} {K:5d} {us:8.1f} {fl / us / 1e6:7.0f} {hb:8.1f} {mf:8.1f} {us / max(hb, mf):6.2f}  {kn} x{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}")
 print(f"forward {tot['F'] / 1e3:.3f} ms, dgrad {tot['D'] / 1e3:.3f} ms per step (production: beside the side stream's weight-gradient GEMMs)")
 wg = [r for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]

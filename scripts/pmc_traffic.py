@@ -18,10 +18,15 @@ sys.path.insert(0, ROOT)
 from bench import source_hash  # noqa: E402
 
 
+def dom(name):
+    """the dominant class: the implicit-GEMM conv forward + dgrad launches (conv_gemm.hip: 128-row and pipelined kernels; conv3x3_c64.hip)"""
+    return "conv_gemm_kernel" in name or "conv3x3_c64_kernel" in name
+
+
 def per_step_kib(directory, counter):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     assert files, f"no counter_collection.csv under {directory}"
-    rows = [r for f in files for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "conv_gemm_kernel" in r["Kernel_Name"]]
+    rows = [r for f in files for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and dom(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     assert len(rows) % 2 == 0 and rows, (len(rows), "expected the same number of conv_gemm launches in the warm-up and the timed step")
     last = rows[len(rows) // 2:]
@@ -32,14 +37,14 @@ fetch_kib, n1 = per_step_kib(sys.argv[1], "FETCH_SIZE")
 write_kib, n2 = per_step_kib(sys.argv[2], "WRITE_SIZE")
 assert n1 == n2, (n1, n2)
 hbm = (2.0 * fetch_kib + write_kib) * 1024.0
-out = {"kernel": f"conv_gemm_kernel ({n1} launches per step: forward + dgrad)",
+out = {"kernel": f"conv_gemm_kernel + conv3x3_c64_kernel ({n1} launches per step: forward + dgrad)",
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python3 bench.py --steps 1 --warmup 1",
        "fetch_size_kib_per_step": fetch_kib, "write_size_kib_per_step": write_kib,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",
        "hbm_bytes_per_step": hbm, "launches_per_step": n1, "hbm_bytes_per_launch": hbm / n1, "source_hash": source_hash()}
 if len(sys.argv) > 4:   # matrix-core busy cycles of the same kernel (one more PMC pass)
     files = glob.glob(os.path.join(sys.argv[4], "**", "*counter_collection.csv"), recursive=True)
-    rows = [r for f in files for r in csv.DictReader(open(f)) if "conv_gemm_kernel" in r["Kernel_Name"]]
+    rows = [r for f in files for r in csv.DictReader(open(f)) if dom(r["Kernel_Name"])]
     by = {}
     for r in rows:
         by.setdefault(r["Counter_Name"], []).append((int(r["Start_Timestamp"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
@@ -61,7 +66,7 @@ if len(sys.argv) > 5:   # production launch time of the same kernel: un-instrume
     rows = [r for r in csv.DictReader(open(sys.argv[5]))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     rows = rows[int(len(rows) * 0.4):]
-    cg = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "conv_gemm_kernel" in r["Kernel_Name"]]
+    cg = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if dom(r["Kernel_Name"])]
     out["production_trace"] = {"source": "rocprofv3 --kernel-trace --stats, python3 bench.py --steps 10 --warmup 1 (side stream on), last 60 % of the dispatches",
                                "conv_gemm_launches": len(cg), "conv_gemm_total_ms": sum(cg) / 1e6, "avg_launch_us": sum(cg) / len(cg) / 1e3}
 with open(sys.argv[3], "w") as f:
