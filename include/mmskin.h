@@ -244,6 +244,18 @@ int mmskin_attention_rows_forward(const float* q, const float* k, const float* v
 int mmskin_attention_rows_backward(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
                                    float* dq, float* dk, float* dv, int B, int H, int L, int Dh, const int64_t* qkv_strides,
                                    const int64_t* o_strides, float scale, float drop_p, uint64_t seed, uint64_t offset, void* stream);
+/* Window attention on an image-major token grid [B][nwy*ws][nwx*ws] (ws*ws <= 64, Dh 32 or 64): window (image, wy, wx) attends over its
+ * ws*ws tokens WHERE THEY SIT -- the kernels of mmskin_attention_rows_* with the window -> token map in their addressing, so timm's
+ * window_partition / window_reverse (davit.py SpatialBlock.forward; reached through loadImageModelClassifier.py:117-131) are index
+ * arithmetic, not copies.  q_tok / q_head: element strides between tokens / heads of q, k, v (and dq, dk, dv); o_tok / o_head of o
+ * (and dO).  lse [B*nwy*nwx][H][ws*ws].  Dropout as mmskin_attention_rows_forward with batch = window index. */
+int mmskin_window_attention_forward(const float* q, const float* k, const float* v, float* o, float* lse, int B, int nwy, int nwx, int ws,
+                                    int H, int Dh, int64_t q_tok, int64_t q_head, int64_t o_tok, int64_t o_head, float scale,
+                                    float drop_p, uint64_t seed, uint64_t offset, void* stream);
+int mmskin_window_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
+                                     float* dq, float* dk, float* dv, int B, int nwy, int nwx, int ws, int H, int Dh, int64_t q_tok,
+                                     int64_t q_head, int64_t o_tok, int64_t o_head, float scale, float drop_p, uint64_t seed,
+                                     uint64_t offset, void* stream);
 /* linear_lane: the lane Linear with a frozen transformer block's elementwise tail fused into the GEMM epilogue,
  *   y = residual + gamma * dropout(act(x w^T + b))     (residual fp32 [M][N], gamma fp32 [N], dropout: the generator of mmskin_dropout_forward
  *   on element row * N + column; each optional).  w is fp32 or an already-converted bf16 copy (w_dtype).  Replaces the nn.Linear ->

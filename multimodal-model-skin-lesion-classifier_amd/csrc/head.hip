@@ -372,44 +372,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// Inference-lane LayerNorm: one wave per row, the row held in registers (N <= 2048, N % 4 == 0: float4 loads, one pass over memory),
-// result written as fp32 and / or bf16 -- the bf16 copy is what the next Linear consumes in bf16-operand mode, so no separate
-// conversion pass runs.  No mean / rstd output: the lane is only taken when no gradient flows.
-__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                                const float* __restrict__ b, float* __restrict__ y32,
-                                                                bf16_t* __restrict__ y16, int M, int N, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* xr = x + (int64_t)row * N;
-  float4 v[8];
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = (j * 64 + lane) * 4;
-    v[j] = i < N ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-  }
-  const float mu = wave_sum(s) / (float)N;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = (j * 64 + lane) * 4;
-    if (i < N) { const float a = v[j].x - mu, c = v[j].y - mu, d = v[j].z - mu, e = v[j].w - mu; q += (a * a + c * c) + (d * d + e * e); }
-  }
-  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)N + eps);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int i = (j * 64 + lane) * 4;
-    if (i >= N) continue;
-    const float4 gg = *reinterpret_cast<const float4*>(g + i), bb = *reinterpret_cast<const float4*>(b + i);
-    const float4 o = make_float4((v[j].x - mu) * rs * gg.x + bb.x, (v[j].y - mu) * rs * gg.y + bb.y,
-                                 (v[j].z - mu) * rs * gg.z + bb.z, (v[j].w - mu) * rs * gg.w + bb.w);
-    if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * N + i) = o;
-    if (y16) *reinterpret_cast<uint2*>(y16 + (int64_t)row * N + i) = make_uint2(f32_to_bf16_bits(o.x) | (f32_to_bf16_bits(o.y) << 16),
-                                                                                f32_to_bf16_bits(o.z) | (f32_to_bf16_bits(o.w) << 16));
-  }
-}
-
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ g, const float* __restrict__ b,
                                                                const float* __restrict__ mean,
@@ -485,6 +447,151 @@ __global__ void layernorm_gb_reduce_kernel(const float* __restrict__ part, float
   if (dg) dg[n] = sg;
   if (db) db[n] = sb;
 }
+
+// Row-in-registers LayerNorm (N % 4 == 0, N <= 2048, no ReLU): LPR lanes own one row (LPR = 32 for N <= 128 so a 64-wide wave
+// carries two rows instead of idling 40 lanes), NJ float4 chunks per lane, ONE pass over memory.
+//   forward : y as fp32 and / or bf16 (what a bf16-operand Linear consumes), mean / rstd when a backward follows
+//   backward: dx AND the lane's running sums of dy * xhat / dy over all the rows it visits -> part[slot][2][N]; a second small
+//             kernel adds the slots.  Replaces dx pass + column pass + serial 1-3 block reduction (94 us per LayerNorm of the
+//             DaViT stage-1 shape, three reads of dy and x) by one read of each.
+template <int LPR> __device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int NJ, int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ b, float* __restrict__ y32,
+                                                                 bf16_t* __restrict__ y16, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int M, int N, float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const bool live = row < M;
+  const float* xr = x + (int64_t)(live ? row : 0) * N;
+  float4 v[NJ];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = (j * LPR + sl) * 4;
+    v[j] = (live && i < N) ? *reinterpret_cast<const float4*>(xr + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mu = row_sum<LPR>(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = (j * LPR + sl) * 4;
+    if (i < N) { const float a = v[j].x - mu, c = v[j].y - mu, d = v[j].z - mu, e = v[j].w - mu; q += (a * a + c * c) + (d * d + e * e); }
+  }
+  const float rs = 1.0f / sqrtf(row_sum<LPR>(q) / (float)N + eps);
+  if (!live) return;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = (j * LPR + sl) * 4;
+    if (i >= N) continue;
+    const float4 gg = *reinterpret_cast<const float4*>(g + i), bb = *reinterpret_cast<const float4*>(b + i);
+    const float4 o = make_float4((v[j].x - mu) * rs * gg.x + bb.x, (v[j].y - mu) * rs * gg.y + bb.y,
+                                 (v[j].z - mu) * rs * gg.z + bb.z, (v[j].w - mu) * rs * gg.w + bb.w);
+    if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * N + i) = o;
+    if (y16) *reinterpret_cast<uint2*>(y16 + (int64_t)row * N + i) = make_uint2(f32_to_bf16_bits(o.x) | (f32_to_bf16_bits(o.y) << 16),
+                                                                                f32_to_bf16_bits(o.z) | (f32_to_bf16_bits(o.w) << 16));
+  }
+  if (sl == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int NJ, int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 const float* __restrict__ g, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ dx,
+                                                                 float* __restrict__ part, int M, int N) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, sl = lane % LPR;
+  const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), nslots = gridDim.x * 4;
+  float4 gg[NJ], ag[NJ], ab[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = (j * LPR + sl) * 4;
+    gg[j] = i < N ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float invN = 1.0f / (float)N;
+  for (int base = slot * RPW; base < M; base += nslots * RPW) {   // wave-uniform trip count: the shuffles below run converged
+    const int row = base + sub;
+    const bool live = row < M;
+    const int64_t off = (int64_t)(live ? row : 0) * N;
+    const float mu = mean[live ? row : 0], rs = rstd[live ? row : 0];
+    float4 xh[NJ], dg[NJ];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = (j * LPR + sl) * 4;
+      const bool ok = live && i < N;
+      const float4 xv = ok ? *reinterpret_cast<const float4*>(x + off + i) : make_float4(mu, mu, mu, mu);
+      const float4 d = ok ? *reinterpret_cast<const float4*>(dy + off + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      dg[j] = make_float4(d.x * gg[j].x, d.y * gg[j].y, d.z * gg[j].z, d.w * gg[j].w);
+      c1 += (dg[j].x + dg[j].y) + (dg[j].z + dg[j].w);
+      c2 += (dg[j].x * xh[j].x + dg[j].y * xh[j].y) + (dg[j].z * xh[j].z + dg[j].w * xh[j].w);
+      ag[j].x += d.x * xh[j].x; ag[j].y += d.y * xh[j].y; ag[j].z += d.z * xh[j].z; ag[j].w += d.w * xh[j].w;
+      ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+    }
+    c1 = row_sum<LPR>(c1) * invN; c2 = row_sum<LPR>(c2) * invN;
+    if (dx && live) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int i = (j * LPR + sl) * 4;
+        if (i < N)
+          *reinterpret_cast<float4*>(dx + off + i) = make_float4(rs * (dg[j].x - c1 - xh[j].x * c2), rs * (dg[j].y - c1 - xh[j].y * c2),
+                                                                 rs * (dg[j].z - c1 - xh[j].z * c2), rs * (dg[j].w - c1 - xh[j].w * c2));
+      }
+    }
+  }
+  if (!part) return;
+  float* pr = part + (int64_t)(slot * RPW + sub) * 2 * N;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int i = (j * LPR + sl) * 4;
+    if (i < N) { *reinterpret_cast<float4*>(pr + i) = ag[j]; *reinterpret_cast<float4*>(pr + N + i) = ab[j]; }
+  }
+}
+// dg[n] = sum_r part[r][0][n], db[n] = sum_r part[r][1][n]: 64 columns x 16 row lanes per block
+__global__ __launch_bounds__(1024) void layernorm_gb_finalize_kernel(const float* __restrict__ part, float* __restrict__ dg,
+                                                                     float* __restrict__ db, int R, int N) {
+  __shared__ float red[2][16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+  if (n < N) {
+    int r = ry;
+    for (; r + 16 < R; r += 32) {
+      s0 += part[(int64_t)r * 2 * N + n]; t0 += part[(int64_t)r * 2 * N + N + n];
+      s1 += part[(int64_t)(r + 16) * 2 * N + n]; t1 += part[(int64_t)(r + 16) * 2 * N + N + n];
+    }
+    if (r < R) { s0 += part[(int64_t)r * 2 * N + n]; t0 += part[(int64_t)r * 2 * N + N + n]; }
+  }
+  red[0][ry][cx] = s0 + s1; red[1][ry][cx] = t0 + t1;
+  __syncthreads();
+  if (ry < 2 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[ry][k][cx];
+    float* out = ry == 0 ? dg : db;
+    if (out) out[n] = t;
+  }
+}
+// NJ / LPR dispatch: N <= 128 -> two rows per wave; else the smallest NJ with 256 * NJ >= N
+#define LN_ROWS_DISPATCH(N, CALL)                                                                   \
+  do {                                                                                              \
+    if ((N) <= 128) { CALL(1, 32); }                                                                \
+    else if ((N) <= 256) { CALL(1, 64); }                                                           \
+    else if ((N) <= 512) { CALL(2, 64); }                                                           \
+    else if ((N) <= 768) { CALL(3, 64); }                                                           \
+    else if ((N) <= 1024) { CALL(4, 64); }                                                          \
+    else if ((N) <= 1536) { CALL(6, 64); }                                                          \
+    else { CALL(8, 64); }                                                                           \
+  } while (0)
+static inline bool ln_rows_ok(int N, int relu) { return !relu && N % 4 == 0 && N <= 2048; }
 
 // ------------------------------------------------------------------ pointwise gates
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -676,7 +783,26 @@ struct AttnRowsArgs {
   int nheads, H, L, Dh;
   float scale, drop_p;
   uint64_t seed, offset;
+  int win_ws, win_nwy, win_nwx;   // > 0: "batch" b is window (image, wy, wx) of a [image][nwy*ws][nwx*ws] token grid, row l its token (l / ws, l % ws)
 };
+// Base offsets of (batch b, head h), the token offset of the lane's row and the stepping of the wave-uniform walk over the other
+// rows (token offset t: ++t, and + wrap after every ws-th row).  Window mode reads / writes the tokens where they sit in the
+// image-major activation: window partition / reverse are this index arithmetic, not copies (timm davit.py window_partition / window_reverse).
+__device__ __forceinline__ void rows_geom(const AttnRowsArgs& p, int b, int h, int row, int64_t& qbase, int64_t& obase, int& lrow,
+                                          int& ws, int& wrap) {
+  if (p.win_ws > 0) {
+    const int nw = p.win_nwy * p.win_nwx, img = b / nw, w = b - img * nw, wy = w / p.win_nwx, wx = w - wy * p.win_nwx;
+    const int Wimg = p.win_nwx * p.win_ws;
+    const int64_t t0 = ((int64_t)img * (p.win_nwy * p.win_ws) + wy * p.win_ws) * Wimg + wx * p.win_ws;
+    qbase = t0 * p.qs_l + h * p.qs_h; obase = t0 * p.os_l + h * p.os_h;
+    lrow = (row / p.win_ws) * Wimg + row % p.win_ws;
+    ws = p.win_ws; wrap = Wimg - p.win_ws;
+  } else {
+    qbase = b * p.qs_b + h * p.qs_h; obase = b * p.os_b + h * p.os_h;
+    lrow = row; ws = 0x7fffffff; wrap = 0;
+  }
+}
+#define ROWS_STEP(t, x) do { ++t; if (++x == g_ws) { x = 0; t += g_wrap; } } while (0)
 
 // (pointers are separate __restrict__ kernel parameters, not struct members: the no-alias guarantee is what lets the compiler turn
 // the wave-uniform key / value reads into scalar loads.  The loops over the OTHER token are rolled -- unrolled, the scheduler hoists
@@ -693,10 +819,13 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
   const int L = p.L;
   float* Ss = rows_lds + (size_t)wave * L * 64 + lane;
   const int b = head / p.H, h = head - b * p.H;
-  const int64_t qbase = b * p.qs_b + h * p.qs_h, obase = b * p.os_b + h * p.os_h;
   const bool act = lane < L;
   const int row = act ? lane : 0;                            // idle lanes shadow row 0; nothing of theirs is stored
-  const float* __restrict__ qrow = gq + qbase + row * p.qs_l;
+  int64_t qbase, obase;
+  int lrow, g_ws, g_wrap;
+  rows_geom(p, b, h, row, qbase, obase, lrow, g_ws, g_wrap);
+  g_ws = __builtin_amdgcn_readfirstlane(g_ws); g_wrap = __builtin_amdgcn_readfirstlane(g_wrap);
+  const float* __restrict__ qrow = gq + qbase + lrow * p.qs_l;
   const float* __restrict__ kb = gk + qbase;
   const float* __restrict__ vb = gv + qbase;
   float qv[DH];
@@ -706,14 +835,16 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
     qv[d] = t.x * p.scale; qv[d + 1] = t.y * p.scale; qv[d + 2] = t.z * p.scale; qv[d + 3] = t.w * p.scale;
   }
   float mx = -INFINITY;
+  int jt = 0, jx = 0;
 #pragma unroll 1
   for (int j = 0; j < L; ++j) {
-    const float* __restrict__ kr = kb + j * p.qs_l;          // uniform address: scalar loads
+    const float* __restrict__ kr = kb + jt * p.qs_l;         // uniform address: scalar loads
     float a = 0.f;
 #pragma unroll
     for (int d = 0; d < DH; ++d) a = fmaf(qv[d], kr[d], a);
     Ss[j * 64] = a;
     mx = fmaxf(mx, a);
+    ROWS_STEP(jt, jx);
   }
   const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const int64_t gi0 = ((int64_t)head * L + row) * L;
@@ -721,9 +852,10 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
 #pragma unroll
   for (int d = 0; d < DH; ++d) ov[d] = 0.f;
   float sum = 0.f;
+  jt = 0; jx = 0;
 #pragma unroll 1
   for (int j = 0; j < L; ++j) {
-    const float* __restrict__ vr = vb + j * p.qs_l;
+    const float* __restrict__ vr = vb + jt * p.qs_l;
     float e = expf(Ss[j * 64] - mx);
     sum += e;                                                // the softmax denominator counts dropped probabilities too
     if (p.drop_p > 0.f) {
@@ -732,11 +864,12 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
     }
 #pragma unroll
     for (int d = 0; d < DH; ++d) ov[d] = fmaf(e, vr[d], ov[d]);
+    ROWS_STEP(jt, jx);
   }
   const float inv = 1.f / sum;
   if (act) {
     if (glse) glse[(int64_t)head * L + lane] = mx + logf(sum);
-    float* __restrict__ orow = gout + obase + row * p.os_l;
+    float* __restrict__ orow = gout + obase + lrow * p.os_l;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) *reinterpret_cast<float4*>(orow + d) = make_float4(ov[d] * inv, ov[d + 1] * inv, ov[d + 2] * inv, ov[d + 3] * inv);
   }
@@ -757,9 +890,12 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
   float* dSs = rows_lds + (size_t)wave * 2 * L * LP;
   float* Pps = dSs + L * LP;
   const int b = head / p.H, h = head - b * p.H;
-  const int64_t qbase = b * p.qs_b + h * p.qs_h, obase = b * p.os_b + h * p.os_h;
   const bool act = lane < L;
   const int row = act ? lane : 0;
+  int64_t qbase, obase;
+  int lrow, g_ws, g_wrap;
+  rows_geom(p, b, h, row, qbase, obase, lrow, g_ws, g_wrap);
+  g_ws = __builtin_amdgcn_readfirstlane(g_ws); g_wrap = __builtin_amdgcn_readfirstlane(g_wrap);
   const float* __restrict__ qb = gq + qbase;
   const float* __restrict__ kb = gk + qbase;
   const float* __restrict__ vb = gv + qbase;
@@ -767,9 +903,9 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
   {
     // ---- phase A: lane i = query row i.  p_ij from the saved row log-sum-exp, dP'_ij = dO_i . v_j, delta_i = dO_i . o_i,
     // dS_ij = p_ij (f_ij dP'_ij - delta_i) scale  (f = dropout factor);  dq_i = sum_j dS_ij k_j
-    const float* __restrict__ qrow = qb + row * p.qs_l;
-    const float* __restrict__ dorow = dob + row * p.os_l;
-    const float* __restrict__ orow = go + obase + row * p.os_l;
+    const float* __restrict__ qrow = qb + lrow * p.qs_l;
+    const float* __restrict__ dorow = dob + lrow * p.os_l;
+    const float* __restrict__ orow = go + obase + lrow * p.os_l;
     float qv[DH], gvv[DH], acc[DH];
     float delta = 0.f;
 #pragma unroll
@@ -785,10 +921,11 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
     const float lse = glse[(int64_t)head * L + row];
     const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     const int64_t gi0 = ((int64_t)head * L + row) * L;
+    int jt = 0, jx = 0;
 #pragma unroll 1
     for (int j = 0; j < L; ++j) {
-      const float* __restrict__ kr = kb + j * p.qs_l;
-      const float* __restrict__ vr = vb + j * p.qs_l;
+      const float* __restrict__ kr = kb + jt * p.qs_l;
+      const float* __restrict__ vr = vb + jt * p.qs_l;
       float a = 0.f, c = 0.f;
 #pragma unroll
       for (int d = 0; d < DH; ++d) { a = fmaf(qv[d], kr[d], a); c = fmaf(gvv[d], vr[d], c); }
@@ -802,9 +939,10 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
       if (act) { dSs[lane * LP + j] = ds; Pps[lane * LP + j] = pj * f; }
 #pragma unroll
       for (int d = 0; d < DH; ++d) acc[d] = fmaf(ds, kr[d], acc[d]);
+      ROWS_STEP(jt, jx);
     }
     if (act) {
-      float* __restrict__ dqrow = gdq + qbase + row * p.qs_l;
+      float* __restrict__ dqrow = gdq + qbase + lrow * p.qs_l;
 #pragma unroll
       for (int d = 0; d < DH; d += 4) *reinterpret_cast<float4*>(dqrow + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
     }
@@ -816,17 +954,19 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
   float ak[DH], av[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+  int it = 0, ix = 0;
 #pragma unroll 1
   for (int i = 0; i < L; ++i) {
     const float dsi = dSs[i * LP + row], ppi = Pps[i * LP + row];
-    const float* __restrict__ qr = qb + i * p.qs_l;          // uniform: scalar loads
-    const float* __restrict__ gr = dob + i * p.os_l;
+    const float* __restrict__ qr = qb + it * p.qs_l;         // uniform: scalar loads
+    const float* __restrict__ gr = dob + it * p.os_l;
 #pragma unroll
     for (int d = 0; d < DH; ++d) { ak[d] = fmaf(dsi, qr[d], ak[d]); av[d] = fmaf(ppi, gr[d], av[d]); }
+    ROWS_STEP(it, ix);
   }
   if (act) {
-    float* __restrict__ dkrow = gdk + qbase + row * p.qs_l;
-    float* __restrict__ dvrow = gdv + qbase + row * p.qs_l;
+    float* __restrict__ dkrow = gdk + qbase + lrow * p.qs_l;
+    float* __restrict__ dvrow = gdv + qbase + lrow * p.qs_l;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) {
       *reinterpret_cast<float4*>(dkrow + d) = make_float4(ak[d], ak[d + 1], ak[d + 2], ak[d + 3]);
@@ -1299,7 +1439,14 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                              int M, int N, float eps, int relu, void* stream) {
   ARG_CHECK(x && g && b && y && mean && rstd && M > 0 && N > 0, "layernorm_forward: bad argument");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y, mean, rstd, M, N, eps, relu);
+  static const bool rows = [] { const char* v = getenv("MMSKIN_LN_ROWS"); return !v || atoi(v) != 0; }();
+  if (rows && ln_rows_ok(N, relu)) {
+#define CALL(NJ, LPR) hipLaunchKernelGGL((layernorm_fwd_rows_kernel<NJ, LPR>), dim3(ceil_div(M, 4 * (64 / LPR))), dim3(256), 0, ST(stream), x, g, b, y, (bf16_t*)nullptr, mean, rstd, M, N, eps)
+    LN_ROWS_DISPATCH(N, CALL);
+#undef CALL
+  } else {
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y, mean, rstd, M, N, eps, relu);
+  }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1307,14 +1454,35 @@ int mmskin_layernorm_forward_mixed(const float* x, const float* g, const float* 
                                    float eps, void* stream) {
   ARG_CHECK(x && g && b && (y_f32 || y_bf16) && M > 0 && N > 0, "layernorm_forward_mixed: bad argument");
   ARG_CHECK(N % 4 == 0 && N <= 2048, "layernorm_forward_mixed: N=%d (needs N %% 4 == 0 and N <= 2048)", N);
-  hipLaunchKernelGGL(layernorm_fwd_vec_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), x, g, b, y_f32,
-                     reinterpret_cast<bf16_t*>(y_bf16), M, N, eps);
+#define CALL(NJ, LPR) hipLaunchKernelGGL((layernorm_fwd_rows_kernel<NJ, LPR>), dim3(ceil_div(M, 4 * (64 / LPR))), dim3(256), 0, ST(stream), x, g, b, y_f32, reinterpret_cast<bf16_t*>(y_bf16), (float*)nullptr, (float*)nullptr, M, N, eps)
+  LN_ROWS_DISPATCH(N, CALL);
+#undef CALL
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, const float* b, const float* mean,
                               const float* rstd, float* dx, float* dg, float* db, int M, int N, int relu, void* stream) {
   ARG_CHECK(dy && x && g && b && mean && rstd && M > 0 && N > 0, "layernorm_backward: bad argument");
+  static const bool rows = [] { const char* v = getenv("MMSKIN_LN_ROWS"); return !v || atoi(v) != 0; }();
+  if (rows && ln_rows_ok(N, relu)) {
+    // <= 1024 workgroups; every wave keeps >= 8 rows so its column sums amortise the slot it writes
+    const int rpw = N <= 128 ? 2 : 1;
+    int G = ceil_div(M, 4 * rpw * 8);
+    if (G > 1024) G = 1024;
+    if (G < 1) G = 1;
+    const int R = G * 4 * rpw;
+    float* part = nullptr;
+    if (dg || db) {
+      part = head_scratch((size_t)R * 2 * N * sizeof(float));
+      if (!part) { mmskin_set_error("layernorm_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    }
+#define CALL(NJ, LPR) hipLaunchKernelGGL((layernorm_bwd_rows_kernel<NJ, LPR>), dim3(G), dim3(256), 0, ST(stream), dy, x, g, mean, rstd, dx, part, M, N)
+    LN_ROWS_DISPATCH(N, CALL);
+#undef CALL
+    if (part) hipLaunchKernelGGL(layernorm_gb_finalize_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, ST(stream), part, dg, db, R, N);
+    HIP_CHECK_RET(hipGetLastError());
+    return MMSKIN_OK;
+  }
   if (dx) {
     hipLaunchKernelGGL(layernorm_bwd_dx_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, ST(stream), dy, x, g, b, mean, rstd, dx, M, N, relu);
     HIP_CHECK_RET(hipGetLastError());
@@ -1405,7 +1573,65 @@ static int attn_rows_args(AttnRowsArgs& a, int B, int H, int L, int Dh, const in
   a.qs_b = qkv_strides[0]; a.qs_h = qkv_strides[1]; a.qs_l = qkv_strides[2];
   a.os_b = o_strides[0]; a.os_h = o_strides[1]; a.os_l = o_strides[2];
   a.nheads = B * H; a.H = H; a.L = L; a.Dh = Dh; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.offset = offset;
+  a.win_ws = 0; a.win_nwy = 0; a.win_nwx = 0;
   return MMSKIN_OK;
+}
+static int attn_rows_fwd_launch(const float* q, const float* k, const float* v, float* o, float* lse, const AttnRowsArgs& a, void* stream) {
+  const size_t lds = (size_t)4 * a.L * 64 * sizeof(float);
+  if (a.Dh == 32) hipLaunchKernelGGL(attention_rows_fwd_kernel<32>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, lse, a);
+  else hipLaunchKernelGGL(attention_rows_fwd_kernel<64>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, lse, a);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+static int attn_rows_bwd_launch(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
+                                float* dq, float* dk, float* dv, const AttnRowsArgs& a, void* stream) {
+  const size_t lds = (size_t)4 * 2 * a.L * (a.L + 1) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {   // up to 4 waves x 2 tiles x 64 x 65 floats
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 65 * 4));
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 65 * 4));
+    attr_done = true;
+  }
+  if (a.Dh == 32) hipLaunchKernelGGL(attention_rows_bwd_kernel<32>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, dO, lse, dq, dk, dv, a);
+  else hipLaunchKernelGGL(attention_rows_bwd_kernel<64>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, dO, lse, dq, dk, dv, a);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+// Window attention on an image-major token grid [B][nwy*ws][nwx*ws] (DaViT SpatialBlock, timm davit.py:window_partition /
+// window_reverse around WindowAttention): window (image, wy, wx) attends over its ws*ws tokens where they sit -- no partition /
+// reverse copies.  token_stride / head_stride: element strides of q / k / v (and dq / dk / dv) and of o (and dO); lse is
+// [B*nwy*nwx][H][ws*ws] (private to the forward / backward pair).
+static int attn_window_args(AttnRowsArgs& a, int B, int nwy, int nwx, int ws, int H, int Dh, int64_t q_tok, int64_t q_head, int64_t o_tok,
+                            int64_t o_head, float scale, float drop_p, uint64_t seed, uint64_t offset, const char* what) {
+  ARG_CHECK(B > 0 && nwy > 0 && nwx > 0 && ws > 0 && ws * ws <= 64, "%s: needs ws*ws <= 64 (ws=%d)", what, ws);
+  ARG_CHECK((int64_t)B * nwy * nwx * H < (int64_t)1 << 30, "%s: too many windows", what);
+  const int64_t qs[3] = {0, q_head, q_tok}, os[3] = {0, o_head, o_tok};
+  int rc = attn_rows_args(a, B * nwy * nwx, H, ws * ws, Dh, qs, os, scale, drop_p, seed, offset, what);
+  if (rc) return rc;
+  a.win_ws = ws; a.win_nwy = nwy; a.win_nwx = nwx;
+  return MMSKIN_OK;
+}
+int mmskin_window_attention_forward(const float* q, const float* k, const float* v, float* o, float* lse, int B, int nwy, int nwx, int ws,
+                                    int H, int Dh, int64_t q_tok, int64_t q_head, int64_t o_tok, int64_t o_head, float scale,
+                                    float drop_p, uint64_t seed, uint64_t offset, void* stream) {
+  ARG_CHECK(q && k && v && o, "window_attention_forward: null argument");
+  ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0, "window_attention_forward: 16-byte aligned tensors required");
+  AttnRowsArgs a;
+  int rc = attn_window_args(a, B, nwy, nwx, ws, H, Dh, q_tok, q_head, o_tok, o_head, scale, drop_p, seed, offset, "window_attention_forward");
+  if (rc) return rc;
+  return attn_rows_fwd_launch(q, k, v, o, lse, a, stream);
+}
+int mmskin_window_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
+                                     float* dq, float* dk, float* dv, int B, int nwy, int nwx, int ws, int H, int Dh, int64_t q_tok,
+                                     int64_t q_head, int64_t o_tok, int64_t o_head, float scale, float drop_p, uint64_t seed,
+                                     uint64_t offset, void* stream) {
+  ARG_CHECK(dO && q && k && v && o && lse && dq && dk && dv, "window_attention_backward: null argument");
+  ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0,
+            "window_attention_backward: 16-byte aligned tensors required");
+  AttnRowsArgs a;
+  int rc = attn_window_args(a, B, nwy, nwx, ws, H, Dh, q_tok, q_head, o_tok, o_head, scale, drop_p, seed, offset, "window_attention_backward");
+  if (rc) return rc;
+  return attn_rows_bwd_launch(dO, q, k, v, o, lse, dq, dk, dv, a, stream);
 }
 int mmskin_attention_rows_forward(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L, int Dh,
                                   const int64_t* qkv_strides, const int64_t* o_strides, float scale, float drop_p, uint64_t seed,
@@ -1415,11 +1641,7 @@ int mmskin_attention_rows_forward(const float* q, const float* k, const float* v
   AttnRowsArgs a;
   int rc = attn_rows_args(a, B, H, L, Dh, qkv_strides, o_strides, scale, drop_p, seed, offset, "attention_rows_forward");
   if (rc) return rc;
-  const size_t lds = (size_t)4 * L * 64 * sizeof(float);
-  if (Dh == 32) hipLaunchKernelGGL(attention_rows_fwd_kernel<32>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, lse, a);
-  else hipLaunchKernelGGL(attention_rows_fwd_kernel<64>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, lse, a);
-  HIP_CHECK_RET(hipGetLastError());
-  return MMSKIN_OK;
+  return attn_rows_fwd_launch(q, k, v, o, lse, a, stream);
 }
 int mmskin_attention_rows_backward(const float* dO, const float* q, const float* k, const float* v, const float* o, const float* lse,
                                    float* dq, float* dk, float* dv, int B, int H, int L, int Dh, const int64_t* qkv_strides,
@@ -1430,17 +1652,7 @@ int mmskin_attention_rows_backward(const float* dO, const float* q, const float*
   AttnRowsArgs a;
   int rc = attn_rows_args(a, B, H, L, Dh, qkv_strides, o_strides, scale, drop_p, seed, offset, "attention_rows_backward");
   if (rc) return rc;
-  const size_t lds = (size_t)4 * 2 * L * (L + 1) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {   // up to 4 waves x 2 tiles x 64 x 65 floats
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 65 * 4));
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_rows_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 65 * 4));
-    attr_done = true;
-  }
-  if (Dh == 32) hipLaunchKernelGGL(attention_rows_bwd_kernel<32>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, dO, lse, dq, dk, dv, a);
-  else hipLaunchKernelGGL(attention_rows_bwd_kernel<64>, dim3((a.nheads + 3) / 4), dim3(256), lds, ST(stream), q, k, v, o, dO, lse, dq, dk, dv, a);
-  HIP_CHECK_RET(hipGetLastError());
-  return MMSKIN_OK;
+  return attn_rows_bwd_launch(dO, q, k, v, o, lse, dq, dk, dv, a, stream);
 }
 
 int mmskin_mdnet_fuse_forward(const float* feat, const float* z, const float* t1, const float* t2, float* pooled,

@@ -1709,10 +1709,107 @@ static inline int dww_strips(size_t opix) {
   if (s > 4096) s = 4096;
   return (int)s;
 }
+// 3x3 / stride 1 (the DaViT position encodings, the stride-1 depthwise layers of MobileNet / EfficientNet): one thread owns one
+// 16-byte channel chunk of whole image ROWS and walks them with a sliding 3x3 window in registers -- one load of dY and three of
+// the input per pixel and chunk (the tapped kernel above: 3 + 9 through L1, two 64-bit divisions per pixel), all nine tap sums
+// in registers, one LDS reduction over the block's row lanes at the end.
+struct DwwRowsPlan { int CW, gy, lanes, rpl, nb; };
+static DwwRowsPlan dww_rows_plan(int N, int H, int CPR) {
+  DwwRowsPlan g;
+  g.CW = CPR <= 32 ? CPR : (CPR % 32 == 0 ? 32 : (CPR % 24 == 0 ? 24 : 32));
+  g.gy = (CPR + g.CW - 1) / g.CW;
+  g.lanes = 256 / g.CW;
+  const int NR = N * H;
+  int want = 512 / g.gy;                      // ~512 workgroups per launch
+  if (want < 1) want = 1;
+  g.rpl = (NR + want * g.lanes - 1) / (want * g.lanes);
+  if (g.rpl < 1) g.rpl = 1;
+  g.nb = (NR + g.lanes * g.rpl - 1) / (g.lanes * g.rpl);
+  return g;
+}
 size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride, int ksize) {
   const int pad = ksize / 2;
   const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
-  return (size_t)dww_strips((size_t)N * OH * OW) * ksize * ksize * C;
+  size_t strips = (size_t)dww_strips((size_t)N * OH * OW);
+  if (stride == 1 && ksize == 3) {            // the row-walking kernel's blocks (either element type)
+    for (int epc = 4; epc <= 8; epc *= 2)
+      if (C % epc == 0) { const size_t nb = (size_t)dww_rows_plan(N, H, C / epc).nb; if (nb > strips) strips = nb; }
+  }
+  return strips * ksize * ksize * C;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_wgrad_rows_kernel(const T* __restrict__ dout, const T* __restrict__ in, int H, int W,
+                                                                int CPR, int CW, int lanes, int rpl, int NR,
+                                                                float* __restrict__ partial) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float dww_red[];          // [lanes][CW * EPC]
+  const int cx = threadIdx.x % CW, ly = threadIdx.x / CW;
+  const int cc = blockIdx.y * CW + cx;
+  const size_t C = (size_t)CPR * EPC;
+  float acc[9][EPC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[t][e] = 0.f;
+  if (ly < lanes && cc < CPR) {
+    for (int k = 0; k < rpl; ++k) {
+      const int row = (blockIdx.x * rpl + k) * lanes + ly;      // = n * H + oy (stride 1, pad 1: the output has the input's geometry)
+      if (row >= NR) break;
+      const int oy = row % H;
+      const T* drow = dout + (size_t)row * W * C + (size_t)cc * EPC;
+      const T* irow = in + (size_t)row * W * C + (size_t)cc * EPC;
+      const bool up = oy > 0, dn = oy + 1 < H;
+      const ptrdiff_t rs = (ptrdiff_t)W * (ptrdiff_t)C;
+      Chunk<T> a[3], b[3], c[3], g;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { a[r].v[e] = 0.f; b[r].v[e] = 0.f; c[r].v[e] = 0.f; }
+      if (up) b[0].load(irow - rs);
+      b[1].load(irow);
+      if (dn) b[2].load(irow + rs);
+      for (int ox = 0; ox < W; ++ox) {
+        const bool right = ox + 1 < W;
+        const T* pr = irow + (size_t)(ox + 1) * C;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) c[r].v[e] = 0.f;
+        if (right) {
+          if (up) c[0].load(pr - rs);
+          c[1].load(pr);
+          if (dn) c[2].load(pr + rs);
+        }
+        g.load(drow + (size_t)ox * C);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            acc[r * 3 + 0][e] += g.v[e] * a[r].v[e];
+            acc[r * 3 + 1][e] += g.v[e] * b[r].v[e];
+            acc[r * 3 + 2][e] += g.v[e] * c[r].v[e];
+          }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { a[r] = b[r]; b[r] = c[r]; }
+      }
+    }
+  }
+  for (int t = 0; t < 9; ++t) {               // reduce the row lanes, one tap at a time
+    if (ly < lanes) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) dww_red[ly * CW * EPC + cx * EPC + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CW * EPC; i += 256) {
+      const int ch = blockIdx.y * CW * EPC + i;
+      if (ch < (int)C) {
+        float s2 = 0.f;
+        for (int l = 0; l < lanes; ++l) s2 += dww_red[l * CW * EPC + i];
+        partial[((size_t)blockIdx.x * 9 + t) * C + ch] = s2;
+      }
+    }
+    __syncthreads();
+  }
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_wgrad_kernel(const T* __restrict__ dout, const T* __restrict__ in, int H, int W,
@@ -1788,6 +1885,15 @@ int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int st
   const int strips = dww_strips(opix);
   const size_t per = (opix + strips - 1) / strips;
   const int CPR = C / EPC, KK = ksize * ksize;
+  static const bool rows_on = [] { const char* v = getenv("MMSKIN_DWW_ROWS"); return !v || atoi(v) != 0; }();
+  if (rows_on && stride == 1 && ksize == 3) {
+    const DwwRowsPlan g = dww_rows_plan(N, H, CPR);
+    hipLaunchKernelGGL(dwconv3_wgrad_rows_kernel<T>, dim3(g.nb, g.gy), dim3(256), (size_t)g.lanes * g.CW * EPC * sizeof(float), st, dout, in,
+                       H, W, CPR, g.CW, g.lanes, g.rpl, N * H, partial);
+    hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(KK * C, 256)), dim3(256), 0, st, partial, g.nb, C, Cv, KK, dw);
+    HIP_CHECK_RET(hipGetLastError());
+    return MMSKIN_OK;
+  }
   hipLaunchKernelGGL(dwconv3_wgrad_kernel<T>, dim3(strips, ceil_div(CPR, DWW_COLS), ksize), dim3(256), 0, st, dout, in, H, W, CPR,
                      stride, ksize, OH, OW, opix, per, partial);
   hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(KK * C, 256)), dim3(256), 0, st, partial, strips, C, Cv, KK, dw);

@@ -441,6 +441,60 @@ class AttentionPackedFn(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+@no_second_order
+class WindowAttentionFn(torch.autograd.Function):
+    """Window attention on the packed qkv of an image-major token grid, qkv [B, Hp, Wp, 3, H, Dh] -> [B, Hp, Wp, H, Dh]: every ws x ws
+    window attends over its own tokens where they sit (mmskin_window_attention_*), so timm's window_partition / window_reverse
+    (davit.py SpatialBlock.forward) cost no copy in either direction."""
+
+    @staticmethod
+    def forward(ctx, qkv, ws, drop_p, seed, offset):
+        import ctypes
+        _need_gpu(qkv, "window_attention")
+        qkv = _f32c(qkv)
+        B, Hp, Wp, three, H, Dh = qkv.shape
+        nwy, nwx = Hp // ws, Wp // ws
+        o = torch.empty((B, Hp, Wp, H, Dh), device=qkv.device, dtype=torch.float32)
+        lse = torch.empty((B * nwy * nwx, H, ws * ws), device=qkv.device, dtype=torch.float32)
+        ctx.rng = (float(drop_p), int(seed), int(offset))
+        ctx.geom = (B, nwy, nwx, ws, H, Dh)
+        step = H * Dh * 4
+        base = qkv.data_ptr()
+        call("mmskin_window_attention_forward", ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step), ptr(o),
+             ptr(lse), B, nwy, nwx, ws, H, Dh, 3 * H * Dh, Dh, H * Dh, Dh, Dh ** -0.5, *ctx.rng, stream())
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        import ctypes
+        qkv, o, lse = ctx.saved_tensors
+        B, nwy, nwx, ws, H, Dh = ctx.geom
+        dO = _f32c(dO)
+        dqkv = torch.empty_like(qkv)
+        step = H * Dh * 4
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        call("mmskin_window_attention_backward", ptr(dO), ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step),
+             ptr(o), ptr(lse), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + step), ctypes.c_void_p(dbase + 2 * step), B, nwy, nwx, ws, H, Dh,
+             3 * H * Dh, Dh, H * Dh, Dh, Dh ** -0.5, *ctx.rng, stream())
+        return dqkv, None, None, None, None
+
+
+def window_attention_ok(qkv, ws):
+    """shapes mmskin_window_attention_* takes: fp32 packed qkv [B, Hp, Wp, 3, H, Dh] on the GPU, Hp / Wp multiples of ws, ws*ws <= 64, Dh 32 / 64"""
+    return (qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 6 and qkv.shape[3] == 3 and qkv.is_contiguous()
+            and qkv.shape[1] % ws == 0 and qkv.shape[2] % ws == 0 and _rows_ok(ws * ws, qkv.shape[5]))
+
+
+def window_attention(qkv, ws, dropout_p=0.0, training=False):
+    """softmax(q k^T / sqrt(Dh)) v inside every ws x ws window of the token grid; qkv [B, Hp, Wp, 3, H, Dh] -> [B, Hp, Wp, H, Dh]."""
+    B, Hp, Wp, _, H, Dh = qkv.shape
+    p = dropout_p if training else 0.0
+    nw = B * (Hp // ws) * (Wp // ws)
+    seed, offset = _dropout_state(p, nw * H * (ws * ws) ** 2)
+    return WindowAttentionFn.apply(qkv, ws, p, seed, offset)
+
+
 def attention_packed(qkv, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     """Attention on the packed output of a fused qkv Linear, qkv [B, L, 3, H, Dh] -> [B, L, H, Dh].  Picks, in order: the fused bf16
     kernel (inference lane), the one-wave-per-head fp32 kernels reading the packed tensor in place (L <= 64, Dh 32 / 64, no mask /

@@ -109,9 +109,17 @@ class _SpatialBlock(nn.Module):
         if ph or pw:
             h = torch.nn.functional.pad(h, (0, 0, 0, pw, 0, ph))
         Hp, Wp = H + ph, W + pw
-        win = h.reshape(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C).contiguous()
-        a = self.attn(win).reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
-        a = a[:, :H, :W, :].contiguous()
+        heads = self.attn.num_heads
+        # qkv and proj are per-token Linears: they run on the image-major token grid, and the attention kernel finds each window's
+        # tokens where they sit (ops.window_attention) -- window_partition / window_reverse of timm's SpatialBlock without copies
+        qkv = self.attn.qkv(h.reshape(B * Hp * Wp, C)).reshape(B, Hp, Wp, 3, heads, C // heads)
+        if ops.window_attention_ok(qkv, ws):
+            a = self.attn.proj(ops.window_attention(qkv, ws).reshape(B * Hp * Wp, C)).reshape(B, Hp, Wp, C)
+        else:
+            win = h.reshape(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C).contiguous()
+            a = self.attn(win).reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
+        if ph or pw:
+            a = a[:, :H, :W, :].contiguous()
         x = self.cpe2(ops.add(shortcut, a))
         m = self.mlp(_layernorm(self.norm2, x.reshape(B * H * W, C)))
         return ops.add(x, m.reshape(B, H, W, C))

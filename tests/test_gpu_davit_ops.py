@@ -1,0 +1,96 @@
+"""-m gpu: the DaViT-specific HIP ops against plain PyTorch fp32 on the same inputs -- depthwise 3x3 position encoding (forward, data
+and weight gradient; the row-walking weight-gradient kernel and the tapped one), window attention that finds each window's tokens in
+the image-major grid (timm davit.py window_partition -> WindowAttention -> window_reverse, reached through
+loadImageModelClassifier.py:117-131), and the row-in-registers LayerNorm at the DaViT / BEiT / BERT widths.
+Tolerances: fp32 kernels, 1e-4 relative to the reference's max (summation order differs)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV
+from mmskin import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _chk(a, b, tol=1e-4):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape
+    assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 96), (3, 7, 9, 192), (1, 56, 56, 96), (5, 3, 4, 384), (2, 1, 1, 768), (2, 28, 28, 100)])
+def test_dwconv3_forward_backward(N, H, W, C):
+    g = torch.Generator().manual_seed(N * 1000 + H + C)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    dy = torch.randn(N, H, W, C, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr.permute(0, 3, 1, 2), wr, padding=1, groups=C).permute(0, 2, 3, 1)
+    y_ref.backward(dy)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = ops.dwconv3(xd, wd)
+    y.backward(dy.to(DEV))
+    _chk(y, y_ref); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad, 2e-4)
+
+
+def test_dwconv3_weight_gradient_tapped_kernel_knob():
+    """MMSKIN_DWW_ROWS=0 keeps the tapped weight-gradient kernel reachable (A/B knob): same cases in a fresh interpreter."""
+    env = dict(os.environ, MMSKIN_DWW_ROWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "forward_backward"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _window_reference(qkv, ws):
+    B, Hp, Wp, _, H, Dh = qkv.shape
+    win = qkv.reshape(B, Hp // ws, ws, Wp // ws, ws, 3, H, Dh).permute(0, 1, 3, 2, 4, 5, 6, 7).reshape(-1, ws * ws, 3, H, Dh)
+    q, k, v = (win[:, :, i].permute(0, 2, 1, 3) for i in range(3))            # [nW, H, L, Dh]
+    p = torch.softmax(q @ k.transpose(-1, -2) * Dh ** -0.5, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3)                                            # [nW, L, H, Dh]
+    return o.reshape(B, Hp // ws, Wp // ws, ws, ws, H, Dh).permute(0, 1, 3, 2, 4, 5, 6).reshape(B, Hp, Wp, H, Dh)
+
+
+@pytest.mark.parametrize("B,Hp,Wp,ws,H,Dh", [(2, 14, 14, 7, 3, 32), (1, 7, 21, 7, 2, 32), (3, 8, 4, 4, 1, 64), (2, 56, 56, 7, 3, 32), (1, 6, 9, 3, 5, 32)])
+def test_window_attention_in_place(B, Hp, Wp, ws, H, Dh):
+    g = torch.Generator().manual_seed(B + Hp * 7 + Wp)
+    qkv = torch.randn(B, Hp, Wp, 3, H, Dh, generator=g)
+    dO = torch.randn(B, Hp, Wp, H, Dh, generator=g)
+    ref_in = qkv.double().requires_grad_(True)
+    o_ref = _window_reference(ref_in, ws)
+    o_ref.backward(dO.double())
+    dev = qkv.to(DEV).requires_grad_(True)
+    assert ops.window_attention_ok(dev, ws)
+    o = ops.window_attention(dev, ws)
+    o.backward(dO.to(DEV))
+    _chk(o, o_ref); _chk(dev.grad, ref_in.grad, 2e-4)
+
+
+def test_window_attention_dropout_mask_is_regenerated_in_backward():
+    """With dropout the backward regenerates the forward's mask from (seed, offset): the gradient of sum(o * c) w.r.t. v is P'^T c with the
+    same P' the forward used, so <dv, v> == sum(o * c) (o is linear in v)."""
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(2, 14, 7, 3, 2, 32, generator=g).to(DEV).requires_grad_(True)
+    c = torch.randn(2, 14, 7, 2, 32, generator=g).to(DEV)
+    o = ops.window_attention(qkv, 7, dropout_p=0.3, training=True)
+    (o * c).sum().backward()
+    lhs = (qkv.grad[:, :, :, 2] * qkv.detach()[:, :, :, 2]).sum().item()
+    rhs = (o.detach() * c).sum().item()
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(rhs)), (lhs, rhs)
+
+
+@pytest.mark.parametrize("M,N", [(1000, 192), (515, 384), (777, 768), (300, 1024), (130, 1536), (3, 128), (70, 256), (12544, 96)])
+def test_layernorm_row_kernels(M, N):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g) * 2 - 0.5; w = torch.rand(N, generator=g) + 0.5; b = torch.randn(N, generator=g) * 0.2
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    dy = torch.randn(M, N, generator=g)
+    F.layer_norm(xr, (N,), wr, br).backward(dy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.layernorm(xd, wd, bd, 1e-5)
+    y.backward(dy.to(DEV))
+    _chk(y, F.layer_norm(x.double(), (N,), w.double(), b.double())); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad, 2e-4); _chk(bd.grad, br.grad, 2e-4)
