@@ -398,7 +398,110 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
     dx[(int64_t)row * N + i] = rs * (d * g[i] - c1 - xh * c2);
   }
 }
+// out[c] = sum_r part[r][c] for c < ncols (c < split -> out0[c], else out1[c - split]; either may be null): 16 columns x 64 row lanes
+// per block -- narrow outputs (96 .. 768 columns) still spread over 6 .. 48 workgroups, and a lane adds R / 64 rows
+__global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ part, int R, int ncols, int split, float* __restrict__ out0,
+                                                        float* __restrict__ out1) {
+  __shared__ float red[64][17];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < ncols) {
+    int r = ry;
+    for (; r + 64 < R; r += 128) { s0 += part[(int64_t)r * ncols + c]; s1 += part[(int64_t)(r + 64) * ncols + c]; }
+    if (r < R) s0 += part[(int64_t)r * ncols + c];
+  }
+  red[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && c < ncols) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) t += red[k][cx];
+    float* out = c < split ? out0 : out1;
+    if (out) out[c < split ? c : c - split] = t;
+  }
+}
+static int rows_sum(const float* part, int R, int ncols, int split, float* out0, float* out1, hipStream_t st) {
+  hipLaunchKernelGGL(rows_sum_kernel, dim3(ceil_div(ncols, 16)), dim3(1024), 0, st, part, R, ncols, split, out0, out1);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+// Column sums with float4 loads: CW chunk columns x (256 / CW) row lanes per block, two rows in flight per lane, one partial row
+// per block, rows_sum adds the blocks.  CVT: the same pass also writes the bf16 copy (row pitch cols_pad, zero pad columns) a
+// bf16-operand GEMM consumes -- Linear backward needs both from dy (bias gradient and the dgrad / wgrad operand), so dy is read once.
+template <bool CVT>
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, int64_t M, int N, int rows_per_block, int CW, int lanes,
+                                                      float* __restrict__ part, bf16_t* __restrict__ out16, int cols_pad) {
+  extern __shared__ float cs_red[];           // [lanes][CW * 4]
+  const int cx = threadIdx.x % CW, ly = threadIdx.x / CW;
+  const int c4 = blockIdx.y * CW + cx, col = c4 * 4;
+  const int ncol4 = (CVT ? cols_pad : N) / 4;
+  const bool real = col < N;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  if (ly < lanes && c4 < ncol4) {
+    int64_t r = r0 + ly;
+    for (; r + lanes < r1; r += 2 * lanes) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (real) { v0 = *reinterpret_cast<const float4*>(x + r * N + col); v1 = *reinterpret_cast<const float4*>(x + (r + lanes) * N + col); }
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      if (CVT) {
+        *reinterpret_cast<uint2*>(out16 + r * cols_pad + col) = make_uint2(f32_to_bf16_bits(v0.x) | (f32_to_bf16_bits(v0.y) << 16), f32_to_bf16_bits(v0.z) | (f32_to_bf16_bits(v0.w) << 16));
+        *reinterpret_cast<uint2*>(out16 + (r + lanes) * cols_pad + col) = make_uint2(f32_to_bf16_bits(v1.x) | (f32_to_bf16_bits(v1.y) << 16), f32_to_bf16_bits(v1.z) | (f32_to_bf16_bits(v1.w) << 16));
+      }
+    }
+    if (r < r1) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (real) v0 = *reinterpret_cast<const float4*>(x + r * N + col);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      if (CVT) *reinterpret_cast<uint2*>(out16 + r * cols_pad + col) = make_uint2(f32_to_bf16_bits(v0.x) | (f32_to_bf16_bits(v0.y) << 16), f32_to_bf16_bits(v0.z) | (f32_to_bf16_bits(v0.w) << 16));
+    }
+    *reinterpret_cast<float4*>(cs_red + ((size_t)ly * CW + cx) * 4) = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CW * 4; i += 256) {
+    const int cc = blockIdx.y * CW * 4 + i;
+    if (cc < N) {
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += cs_red[(size_t)l * CW * 4 + i];
+      part[(int64_t)blockIdx.x * N + cc] = t;
+    }
+  }
+}
+struct Colsum4Plan { int CW, lanes, gy, nbx, rpb; };
+static inline Colsum4Plan colsum4_plan(int64_t M, int ncol4) {
+  Colsum4Plan g;
+  g.CW = ncol4 <= 32 ? ncol4 : 32;
+  g.lanes = 256 / g.CW;
+  g.gy = ceil_div(ncol4, g.CW);
+  int64_t want = 1024 / g.gy;
+  if (want < 1) want = 1;
+  int64_t rpb = (M + want - 1) / want;
+  const int64_t lo = (int64_t)g.lanes * 4;                  // a lane adds at least four rows
+  if (rpb < lo) rpb = lo;
+  g.rpb = (int)rpb;
+  g.nbx = (int)((M + rpb - 1) / rpb);
+  return g;
+}
+static inline size_t colsum4_part_bytes(int N) { return (size_t)1024 * N * sizeof(float); }
+// out[N] = column sums of x [M][N]; out16 != null: also the bf16 copy [M][cols_pad].  part: colsum4_part_bytes(N) of scratch.
+static int colsum4(const float* x, float* out, int64_t M, int N, float* part, bf16_t* out16, int cols_pad, hipStream_t st) {
+  const Colsum4Plan g = colsum4_plan(M, (out16 ? cols_pad : N) / 4);
+  const size_t lds = (size_t)g.lanes * g.CW * 4 * sizeof(float);
+  if (out16) hipLaunchKernelGGL(colsum4_kernel<true>, dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad);
+  else hipLaunchKernelGGL(colsum4_kernel<false>, dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad);
+  HIP_CHECK_RET(hipGetLastError());
+  return rows_sum(part, g.nbx, N, N, out, nullptr, st);
+}
 static int colsum(const float* x, float* out, int M, int N, hipStream_t st) {
+  static const bool c4 = [] { const char* v = getenv("MMSKIN_COLSUM4"); return !v || atoi(v) != 0; }();
+  if (c4 && N % 4 == 0 && M >= 2048) {
+    float* part = head_scratch(colsum4_part_bytes(N));
+    if (!part) { mmskin_set_error("colsum: scratch allocation failed"); return MMSKIN_ERR_HIP; }
+    return colsum4(x, out, M, N, part, nullptr, 0, st);
+  }
   const int G = M >= 2048 ? (M / 256 > 128 ? 128 : M / 256) : 1;
   if (G <= 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, x, out, M, N, M);
@@ -548,36 +651,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const float* __
     }
   }
   if (!part) return;
-  float* pr = part + (int64_t)(slot * RPW + sub) * 2 * N;
+  // the block's 4 * RPW row groups meet in LDS (gamma sums, then beta sums through the same buffer): one partial row per block
+  __shared__ float red[4 * RPW][NJ * LPR * 4];
+  const int wv = (threadIdx.x >> 6) * RPW + sub;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int i = (j * LPR + sl) * 4;
-    if (i < N) { *reinterpret_cast<float4*>(pr + i) = ag[j]; *reinterpret_cast<float4*>(pr + N + i) = ab[j]; }
-  }
-}
-// dg[n] = sum_r part[r][0][n], db[n] = sum_r part[r][1][n]: 64 columns x 16 row lanes per block
-__global__ __launch_bounds__(1024) void layernorm_gb_finalize_kernel(const float* __restrict__ part, float* __restrict__ dg,
-                                                                     float* __restrict__ db, int R, int N) {
-  __shared__ float red[2][16][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cx;
-  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
-  if (n < N) {
-    int r = ry;
-    for (; r + 16 < R; r += 32) {
-      s0 += part[(int64_t)r * 2 * N + n]; t0 += part[(int64_t)r * 2 * N + N + n];
-      s1 += part[(int64_t)(r + 16) * 2 * N + n]; t1 += part[(int64_t)(r + 16) * 2 * N + N + n];
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int i = (j * LPR + sl) * 4;
+      if (i < N) *reinterpret_cast<float4*>(&red[wv][i]) = which ? ab[j] : ag[j];
     }
-    if (r < R) { s0 += part[(int64_t)r * 2 * N + n]; t0 += part[(int64_t)r * 2 * N + N + n]; }
-  }
-  red[0][ry][cx] = s0 + s1; red[1][ry][cx] = t0 + t1;
-  __syncthreads();
-  if (ry < 2 && n < N) {
-    float t = 0.f;
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+      float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[ry][k][cx];
-    float* out = ry == 0 ? dg : db;
-    if (out) out[n] = t;
+      for (int r = 0; r < 4 * RPW; ++r) t += red[r][n];
+      part[((int64_t)blockIdx.x * 2 + which) * N + n] = t;
+    }
+    __syncthreads();
   }
 }
 // NJ / LPR dispatch: N <= 128 -> two rows per wave; else the smallest NJ with 256 * NJ >= N
@@ -1360,11 +1451,15 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     const int Kp = pad64(K), Np = pad64(N);
     ConvShape s = {M, 1, 1, Kp, Np, 1, 1, 1, 0};
     const size_t gb = align_up((size_t)M * Np * 2, 256), xb = align_up((size_t)M * Kp * 2, 256), wb = align_up((size_t)Np * Kp * 2, 256);
-    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + align_up(conv_wgrad_slab_bytes(s), 256)));
+    const size_t slb = align_up(conv_wgrad_slab_bytes(s), 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + slb + colsum4_part_bytes(N)));
     if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
     bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
     float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
-    if ((rc = cvt_to_bf16_pad(g, g16, M, N, M, Np, st))) return rc;
+    if (db) {   // bias gradient from the pass that converts dy
+      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, Np, st))) return rc;
+      db = nullptr;
+    } else if ((rc = cvt_to_bf16_pad(g, g16, M, N, M, Np, st))) return rc;
     if (dx) {
       ARG_CHECK(w, "linear_backward: w required for dx");
       HIP_CHECK_RET(hipMemsetAsync(w16, 0, (size_t)Np * Kp * 2, st));
@@ -1384,11 +1479,15 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
   if (linear_big(M, K, N) && linear_bf16()) {
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
     const size_t gb = align_up((size_t)M * N * 2, 256), xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
-    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + align_up(conv_wgrad_slab_bytes(s), 256)));
+    const size_t slb = align_up(conv_wgrad_slab_bytes(s), 256);
+    unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(gb + xb + wb + slb + colsum4_part_bytes(N)));
     if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
     bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
     float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
-    if ((rc = cvt_to_bf16(g, g16, (int64_t)M * N, st))) return rc;
+    if (db) {   // bias gradient from the pass that converts dy
+      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, N, st))) return rc;
+      db = nullptr;
+    } else if ((rc = cvt_to_bf16(g, g16, (int64_t)M * N, st))) return rc;
     if (dx) {
       ARG_CHECK(w, "linear_backward: w required for dx");
       hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3(ceil_div(K, 32), ceil_div(N, 32)), dim3(32, 8), 0, st, w, w16, N, K);
@@ -1470,7 +1569,7 @@ int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, c
     int G = ceil_div(M, 4 * rpw * 8);
     if (G > 1024) G = 1024;
     if (G < 1) G = 1;
-    const int R = G * 4 * rpw;
+    const int R = G;
     float* part = nullptr;
     if (dg || db) {
       part = head_scratch((size_t)R * 2 * N * sizeof(float));
@@ -1479,8 +1578,8 @@ int mmskin_layernorm_backward(const float* dy, const float* x, const float* g, c
 #define CALL(NJ, LPR) hipLaunchKernelGGL((layernorm_bwd_rows_kernel<NJ, LPR>), dim3(G), dim3(256), 0, ST(stream), dy, x, g, mean, rstd, dx, part, M, N)
     LN_ROWS_DISPATCH(N, CALL);
 #undef CALL
-    if (part) hipLaunchKernelGGL(layernorm_gb_finalize_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, ST(stream), part, dg, db, R, N);
     HIP_CHECK_RET(hipGetLastError());
+    if (part) return rows_sum(part, R, 2 * N, N, dg, db, ST(stream));
     return MMSKIN_OK;
   }
   if (dx) {

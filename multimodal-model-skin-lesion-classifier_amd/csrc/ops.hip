@@ -1874,6 +1874,25 @@ __global__ void dwconv3_wgrad_finalize_kernel(const float* __restrict__ partial,
   for (int k = 0; k < nstrips; ++k) s += (double)partial[(size_t)k * KK * C + i];
   if (c < Cv) dw[(size_t)c * KK + t] = (float)s;
 }
+// the same sum with 16 strip lanes per (tap, channel) column: the row-walking kernel leaves a few hundred partial rows
+__global__ __launch_bounds__(1024) void dwconv3_wgrad_finalize_lanes_kernel(const float* __restrict__ partial, int nstrips, int C, int Cv,
+                                                                            int KK, float* __restrict__ dw) {
+  __shared__ double red[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + cx;   // over KK * C: (tap, c)
+  double s = 0.0;
+  if (i < KK * C)
+    for (int k = ry; k < nstrips; k += 16) s += (double)partial[(size_t)k * KK * C + i];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && i < KK * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    const int tp = i / C, c = i - tp * C;
+    if (c < Cv) dw[(size_t)c * KK + tp] = (float)t;
+  }
+}
 template <typename T>
 int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
                   int Cv, hipStream_t st, int ksize) {
@@ -1890,7 +1909,7 @@ int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int st
     const DwwRowsPlan g = dww_rows_plan(N, H, CPR);
     hipLaunchKernelGGL(dwconv3_wgrad_rows_kernel<T>, dim3(g.nb, g.gy), dim3(256), (size_t)g.lanes * g.CW * EPC * sizeof(float), st, dout, in,
                        H, W, CPR, g.CW, g.lanes, g.rpl, N * H, partial);
-    hipLaunchKernelGGL(dwconv3_wgrad_finalize_kernel, dim3(ceil_div(KK * C, 256)), dim3(256), 0, st, partial, g.nb, C, Cv, KK, dw);
+    hipLaunchKernelGGL(dwconv3_wgrad_finalize_lanes_kernel, dim3(ceil_div(KK * C, 64)), dim3(1024), 0, st, partial, g.nb, C, Cv, KK, dw);
     HIP_CHECK_RET(hipGetLastError());
     return MMSKIN_OK;
   }

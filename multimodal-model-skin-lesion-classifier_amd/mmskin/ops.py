@@ -495,6 +495,52 @@ def window_attention(qkv, ws, dropout_p=0.0, training=False):
     return WindowAttentionFn.apply(qkv, ws, p, seed, offset)
 
 
+@no_second_order
+class ChannelAttentionFn(torch.autograd.Function):
+    """DaViT channel attention on the packed qkv of a fused Linear, qkv [B, N, 3, G, 32] -> [B, N, G, 32] (token-major, what the output
+    projection reads): A = softmax(scale q^T k) over each group's 32 channels, x = (A v^T)^T (timm davit.py ChannelAttention.forward).
+    No permute / contiguous copies; the backward writes d(qkv) in the packed layout."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        import ctypes
+        _need_gpu(qkv, "channel_attention")
+        qkv = _f32c(qkv)
+        B, N, three, G, Dh = qkv.shape
+        x = torch.empty((B, N, G, Dh), device=qkv.device, dtype=torch.float32)
+        attn = torch.empty((B * G, Dh, Dh), device=qkv.device, dtype=torch.float32)
+        step = G * Dh * 4
+        base = qkv.data_ptr()
+        ctx.scale = float(scale)
+        call("mmskin_channel_attention_forward", ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step), ptr(x),
+             ptr(attn), B, G, N, Dh, 3 * G * Dh, N * 3 * G * Dh, G * Dh, N * G * Dh, ctx.scale, stream())
+        ctx.save_for_backward(qkv, attn)
+        return x
+
+    @staticmethod
+    def backward(ctx, dO):
+        import ctypes
+        qkv, attn = ctx.saved_tensors
+        B, N, three, G, Dh = qkv.shape
+        dO = _f32c(dO)
+        dqkv = torch.empty_like(qkv)
+        step = G * Dh * 4
+        base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        call("mmskin_channel_attention_backward", ptr(dO), ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step),
+             ptr(attn), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + step), ctypes.c_void_p(dbase + 2 * step), B, G, N, Dh,
+             3 * G * Dh, N * 3 * G * Dh, G * Dh, N * G * Dh, ctx.scale, stream())
+        return dqkv, None
+
+
+def channel_attention_ok(qkv):
+    """shapes mmskin_channel_attention_* takes: fp32 packed qkv [B, N, 3, G, 32] on the GPU"""
+    return qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[4] == 32 and qkv.is_contiguous()
+
+
+def channel_attention(qkv, scale):
+    return ChannelAttentionFn.apply(qkv, scale)
+
+
 def attention_packed(qkv, dropout_p=0.0, training=False, mask_add=None, bias=None, causal=False):
     """Attention on the packed output of a fused qkv Linear, qkv [B, L, 3, H, Dh] -> [B, L, H, Dh].  Picks, in order: the fused bf16
     kernel (inference lane), the one-wave-per-head fp32 kernels reading the packed tensor in place (L <= 64, Dh 32 / 64, no mask /

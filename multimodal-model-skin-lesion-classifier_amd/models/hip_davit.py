@@ -82,7 +82,10 @@ class _ChannelAttention(nn.Module):
     def forward(self, x, B, N):       # x [B*N, C]
         C = x.shape[1]
         G, Dh = self.groups, x.shape[1] // self.groups
-        qkv = self.qkv(x).reshape(B, N, 3, G, Dh).permute(2, 0, 3, 4, 1).contiguous()      # [3, B, G, Dh, N]: channels attend over tokens
+        qkv = self.qkv(x).reshape(B, N, 3, G, Dh)
+        if ops.channel_attention_ok(qkv):     # token-major in and out: no transposing copies around the attention
+            return self.proj(ops.channel_attention(qkv, N ** -0.5).reshape(B * N, C))
+        qkv = qkv.permute(2, 0, 3, 4, 1).contiguous()      # [3, B, G, Dh, N]: channels attend over tokens
         # softmax((q * N^-0.5)^T k) over the key channels, applied to v^T: an attention with "sequence" = the Dh channels of a
         # group and "feature" = the N tokens; ops.attention scales by feature^-0.5 = N^-0.5, exactly timm's dynamic_scale
         o = ops.attention(qkv[0], qkv[1], qkv[2])                                          # [B, G, Dh, N]

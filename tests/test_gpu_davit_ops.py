@@ -94,3 +94,29 @@ def test_layernorm_row_kernels(M, N):
     y = ops.layernorm(xd, wd, bd, 1e-5)
     y.backward(dy.to(DEV))
     _chk(y, F.layer_norm(x.double(), (N,), w.double(), b.double())); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad, 2e-4); _chk(bd.grad, br.grad, 2e-4)
+
+
+def _channel_reference(qkv, scale):
+    B, N, _, G, Dh = qkv.shape
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))            # [B, G, N, Dh]
+    a = torch.softmax((q * scale).transpose(-1, -2) @ k, dim=-1)               # [B, G, Dh, Dh]
+    x = (a @ v.transpose(-1, -2)).transpose(-1, -2)                            # [B, G, N, Dh]
+    return x.permute(0, 2, 1, 3)                                               # [B, N, G, Dh]
+
+
+@pytest.mark.parametrize("B,N,G", [(2, 49, 3), (1, 196, 12), (3, 7, 1), (2, 3136, 3), (1, 1, 2), (2, 50, 24)])
+def test_channel_attention_token_major(B, N, G):
+    """timm davit.py ChannelAttention.forward (dynamic_scale: q * N^-0.5) on the packed [B, N, 3, G, 32] qkv, against the same math in
+    fp64 with explicit permutes: output, and d(qkv) through softmax and both products.  Odd token counts (the MFMA walks token pairs)."""
+    g = torch.Generator().manual_seed(B * 100 + N + G)
+    qkv = torch.randn(B, N, 3, G, 32, generator=g)
+    dO = torch.randn(B, N, G, 32, generator=g)
+    scale = N ** -0.5
+    ref_in = qkv.double().requires_grad_(True)
+    x_ref = _channel_reference(ref_in, scale)
+    x_ref.backward(dO.double())
+    dev = qkv.to(DEV).requires_grad_(True)
+    assert ops.channel_attention_ok(dev)
+    x = ops.channel_attention(dev, scale)
+    x.backward(dO.to(DEV))
+    _chk(x, x_ref); _chk(dev.grad, ref_in.grad, 2e-4)
