@@ -260,12 +260,14 @@ int mmskin_window_attention_backward(const float* dO, const float* q, const floa
  * token-major operands: per (batch, group of Dh = 32 channels)  A = softmax(scale * q^T k) [32 x 32] (the reduction runs over the N tokens),
  * x[n][i] = sum_j A[i][j] v[n][j].  q / k / v (and dq / dk / dv): element strides q_tok between tokens and q_b between batches, group g
  * at channel offset 32 g -- the packed [B, N, 3, G, 32] output of a fused qkv Linear is read in place; x / dO likewise with o_tok / o_b.
- * attn [B*G][32][32] is written by the forward and read by the backward (may be null when no backward follows). */
-int mmskin_channel_attention_forward(const float* q, const float* k, const float* v, float* x, float* attn, int B, int G, int N, int Dh,
-                                     int64_t q_tok, int64_t q_b, int64_t o_tok, int64_t o_b, float scale, void* stream);
+ * attn [B*G][32][32] is written by the forward and read by the backward (may be null when no backward follows).
+ * scratch: mmskin_channel_attention_scratch_floats(B, G, N) floats (0 for N <= 256: may be null) -- per-chunk partial products. */
+int64_t mmskin_channel_attention_scratch_floats(int B, int G, int N);
+int mmskin_channel_attention_forward(const float* q, const float* k, const float* v, float* x, float* attn, float* scratch, int B, int G,
+                                     int N, int Dh, int64_t q_tok, int64_t q_b, int64_t o_tok, int64_t o_b, float scale, void* stream);
 int mmskin_channel_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* attn, float* dq,
-                                      float* dk, float* dv, int B, int G, int N, int Dh, int64_t q_tok, int64_t q_b, int64_t o_tok,
-                                      int64_t o_b, float scale, void* stream);
+                                      float* dk, float* dv, float* scratch, int B, int G, int N, int Dh, int64_t q_tok, int64_t q_b,
+                                      int64_t o_tok, int64_t o_b, float scale, void* stream);
 /* linear_lane: the lane Linear with a frozen transformer block's elementwise tail fused into the GEMM epilogue,
  *   y = residual + gamma * dropout(act(x w^T + b))     (residual fp32 [M][N], gamma fp32 [N], dropout: the generator of mmskin_dropout_forward
  *   on element row * N + column; each optional).  w is fp32 or an already-converted bf16 copy (w_dtype).  Replaces the nn.Linear ->

@@ -16,6 +16,10 @@
 //   phase 3  one thread per token: x[n][:] = A v[n][:] with the matrix read as LDS broadcasts (every lane the same address).
 // Backward: dA = dO^T v (phase 1 with dO in q's place), dS = A . (dA - rowsum(dA . A)) * scale, then per token
 //   dv[n] = A^T dO[n],  dq[n] = dS k[n],  dk[n] = dS^T q[n]   -- three 32 x 32 matrix-vector products against LDS-resident matrices.
+// More than CHAN_CHUNK tokens (DaViT stages 1 - 2: 3 136 / 784 tokens but only 192 / 384 (batch, group) pairs): the token range is cut
+// into chunks of CHAN_CHUNK -- chan_outer_kernel writes one partial 32 x 32 product per (batch, group, chunk), and the apply kernels,
+// one workgroup per chunk, add the partials (every chunk repeats the 32-row softmax) and handle their own tokens.  One workgroup per
+// pair walked 392 dependent MFMA steps per wave behind 4-byte loads: 200 us forward / 250 us backward per launch on average.
 // Deterministic (fixed summation order), no atomics.
 #include "../../include/mmskin.h"
 #include <stdlib.h>
@@ -33,7 +37,9 @@ struct ChanArgs {
   int64_t o_tok, o_b;   // of x (and dO)
   int G, N;
   float scale;
+  int nchunk;           // > 1: partial products in `part`, blockIdx.y = chunk
 };
+#define CHAN_CHUNK 256
 
 // sum_n a[n][i] * b[n][j] over the workgroup's tokens -> red[0][i][j] (all threads return after the barrier)
 __device__ __forceinline__ void tokens_outer_32x32(const float* __restrict__ a, int64_t a_tok, const float* __restrict__ b, int64_t b_tok,
@@ -42,13 +48,17 @@ __device__ __forceinline__ void tokens_outer_32x32(const float* __restrict__ a, 
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-  for (int n0 = wave * 2; n0 < N; n0 += 8) {
-    const int n = n0 + lh;
-    const bool ok = n < N;
-    const float av = ok ? a[(int64_t)n * a_tok + li] : 0.f;
-    const float bv = ok ? b[(int64_t)n * b_tok + li] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  for (int base = 0; base < N; base += 64) {                  // 64 tokens per trip: 8 token pairs per wave, their 16 loads in flight together
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = base + 8 * u + wave * 2 + lh;
+      const bool ok = n < N;
+      av[u] = ok ? a[(int64_t)n * a_tok + li] : 0.f;
+      bv[u] = ok ? b[(int64_t)n * b_tok + li] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
   // D[i][j]: j = lane % 32, i = 8 * (r / 4) + 4 * (lane / 32) + r % 4
 #pragma unroll
@@ -61,18 +71,31 @@ __device__ __forceinline__ void tokens_outer_32x32(const float* __restrict__ a, 
   __syncthreads();
 }
 
-// out[c] = sum_r M[r][c] * in[r]   (M in LDS, row pitch 32 floats: every lane reads the same 16 bytes -> broadcast)
+// out[c] = sum_r M[r][c] * in[r]   (M in LDS, row pitch 32 floats: every lane reads the same 16 bytes -> broadcast).
+// The matrix is loop-invariant for the caller's token loop: left alone, the compiler hoists all 256 b128 reads (1024 registers' worth)
+// out of it and spills them to scratch (the first build: 200 us per launch in this function alone).  The compiler-level memory fences
+// pin each row's reads to their place -- row r + 1 is in flight while row r is multiplied, nothing more.
 __device__ __forceinline__ void matvec32(const float (*M)[32], const float (&in)[32], float (&out)[32]) {
 #pragma unroll
   for (int c = 0; c < 32; ++c) out[c] = 0.f;
+  float4 m[8], nx[8];
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 8; ++c) m[c] = *reinterpret_cast<const float4*>(&M[0][4 * c]);
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
+    if (r + 1 < 32) {
 #pragma unroll
-    for (int c = 0; c < 32; c += 4) {
-      const float4 m = *reinterpret_cast<const float4*>(&M[r][c]);
-      out[c] = fmaf(m.x, in[r], out[c]); out[c + 1] = fmaf(m.y, in[r], out[c + 1]);
-      out[c + 2] = fmaf(m.z, in[r], out[c + 2]); out[c + 3] = fmaf(m.w, in[r], out[c + 3]);
+      for (int c = 0; c < 8; ++c) nx[c] = *reinterpret_cast<const float4*>(&M[r + 1][4 * c]);
     }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      out[4 * c] = fmaf(m[c].x, in[r], out[4 * c]); out[4 * c + 1] = fmaf(m[c].y, in[r], out[4 * c + 1]);
+      out[4 * c + 2] = fmaf(m[c].z, in[r], out[4 * c + 2]); out[4 * c + 3] = fmaf(m[c].w, in[r], out[4 * c + 3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = nx[c];
   }
 }
 __device__ __forceinline__ void load_row32(const float* __restrict__ p, float (&v)[32]) {
@@ -87,14 +110,37 @@ __device__ __forceinline__ void store_row32(float* __restrict__ p, const float (
   for (int c = 0; c < 32; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
 }
 
+// part[(bg * nchunk + chunk)][32][32] = sum over the chunk's tokens of a[n][i] * b[n][j]
+__global__ __launch_bounds__(256) void chan_outer_kernel(const float* __restrict__ a, int64_t a_tok, int64_t a_b, const float* __restrict__ b,
+                                                         int64_t b_tok, int64_t b_b, float* __restrict__ part, int G, int N, int nchunk) {
+  __shared__ float red[4][32][33];
+  const int bg = blockIdx.x, bi = bg / G, g = bg - bi * G, c = blockIdx.y;
+  const int n0 = c * CHAN_CHUNK, cnt = min(N - n0, CHAN_CHUNK);
+  tokens_outer_32x32(a + bi * a_b + (int64_t)g * 32 + (int64_t)n0 * a_tok, a_tok, b + bi * b_b + (int64_t)g * 32 + (int64_t)n0 * b_tok, b_tok, cnt, red);
+  float* out = part + ((int64_t)bg * nchunk + c) * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) out[e] = red[0][e >> 5][e & 31];
+}
+// red[0] = sum of the pair's partial products (chunk order)
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int bg, int nchunk, float (*red)[32][33]) {
+  const float* src = part + (int64_t)bg * nchunk * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) {
+    float t = 0.f;
+    for (int c = 0; c < nchunk; ++c) t += src[(int64_t)c * 1024 + e];
+    red[0][e >> 5][e & 31] = t;
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void channel_attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, float* __restrict__ x,
-                                                               float* __restrict__ attn, const ChanArgs p) {
+                                                               float* __restrict__ attn, const float* __restrict__ part, const ChanArgs p) {
   __shared__ float red[4][32][33];
   __shared__ __attribute__((aligned(16))) float AT[32][32];      // AT[j][i] = A[i][j]
   const int bg = blockIdx.x, b = bg / p.G, g = bg - b * p.G;
   const int64_t qoff = b * p.q_b + (int64_t)g * 32, ooff = b * p.o_b + (int64_t)g * 32;
-  tokens_outer_32x32(q + qoff, p.q_tok, k + qoff, p.q_tok, p.N, red);
+  const int n_begin = blockIdx.y * CHAN_CHUNK, n_end = p.nchunk > 1 ? min(p.N, n_begin + CHAN_CHUNK) : p.N;
+  if (p.nchunk > 1) sum_partials(part, bg, p.nchunk, red);
+  else tokens_outer_32x32(q + qoff, p.q_tok, k + qoff, p.q_tok, p.N, red);
   if (threadIdx.x < 32) {
     const int i = threadIdx.x;
     float mx = -INFINITY;
@@ -108,11 +154,11 @@ __global__ __launch_bounds__(256) void channel_attn_fwd_kernel(const float* __re
     for (int j = 0; j < 32; ++j) {
       const float a = red[1][i][j] * inv;
       AT[j][i] = a;
-      if (attn) attn[((int64_t)bg * 32 + i) * 32 + j] = a;
+      if (attn && blockIdx.y == 0) attn[((int64_t)bg * 32 + i) * 32 + j] = a;
     }
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < p.N; n += 256) {
+  for (int n = n_begin + threadIdx.x; n < n_end; n += 256) {
     float vin[32], out[32];
     load_row32(v + qoff + (int64_t)n * p.q_tok, vin);
     matvec32(AT, vin, out);                                      // out[i] = sum_j AT[j][i] v[j]
@@ -123,12 +169,15 @@ __global__ __launch_bounds__(256) void channel_attn_fwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void channel_attn_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ q,
                                                                const float* __restrict__ k, const float* __restrict__ v,
                                                                const float* __restrict__ attn, float* __restrict__ dq,
-                                                               float* __restrict__ dk, float* __restrict__ dv, const ChanArgs p) {
+                                                               float* __restrict__ dk, float* __restrict__ dv,
+                                                               const float* __restrict__ part, const ChanArgs p) {
   __shared__ float red[4][32][33];
   __shared__ __attribute__((aligned(16))) float A[32][32], dS[32][32], dST[32][32];
   const int bg = blockIdx.x, b = bg / p.G, g = bg - b * p.G;
   const int64_t qoff = b * p.q_b + (int64_t)g * 32, ooff = b * p.o_b + (int64_t)g * 32;
-  tokens_outer_32x32(dO + ooff, p.o_tok, v + qoff, p.q_tok, p.N, red);          // dA[i][j] = sum_n dO[n][i] v[n][j]
+  const int n_begin = blockIdx.y * CHAN_CHUNK, n_end = p.nchunk > 1 ? min(p.N, n_begin + CHAN_CHUNK) : p.N;
+  if (p.nchunk > 1) sum_partials(part, bg, p.nchunk, red);
+  else tokens_outer_32x32(dO + ooff, p.o_tok, v + qoff, p.q_tok, p.N, red);     // dA[i][j] = sum_n dO[n][i] v[n][j]
   if (threadIdx.x < 32) {
     const int i = threadIdx.x;
     const float* ar = attn + ((int64_t)bg * 32 + i) * 32;
@@ -142,7 +191,7 @@ __global__ __launch_bounds__(256) void channel_attn_bwd_kernel(const float* __re
     }
   }
   __syncthreads();
-  for (int n = threadIdx.x; n < p.N; n += 256) {
+  for (int n = n_begin + threadIdx.x; n < n_end; n += 256) {
     float in[32], out[32];
     load_row32(dO + ooff + (int64_t)n * p.o_tok, in);
     matvec32(A, in, out);                                        // dv[j] = sum_i A[i][j] dO[i]
@@ -161,6 +210,7 @@ int chan_args(ChanArgs& a, int B, int G, int N, int Dh, int64_t q_tok, int64_t q
   ARG_CHECK((int64_t)B * G < (int64_t)1 << 30, "%s: too many (batch, group) pairs", what);
   ARG_CHECK(q_tok % 4 == 0 && q_b % 4 == 0 && o_tok % 4 == 0 && o_b % 4 == 0, "%s: strides must keep rows 16-byte aligned", what);
   a.q_tok = q_tok; a.q_b = q_b; a.o_tok = o_tok; a.o_b = o_b; a.G = G; a.N = N; a.scale = scale;
+  a.nchunk = (N + CHAN_CHUNK - 1) / CHAN_CHUNK;
   return MMSKIN_OK;
 }
 
@@ -168,28 +218,37 @@ int chan_args(ChanArgs& a, int B, int G, int N, int Dh, int64_t q_tok, int64_t q
 
 extern "C" {
 
-int mmskin_channel_attention_forward(const float* q, const float* k, const float* v, float* x, float* attn, int B, int G, int N, int Dh,
-                                     int64_t q_tok, int64_t q_b, int64_t o_tok, int64_t o_b, float scale, void* stream) {
+int64_t mmskin_channel_attention_scratch_floats(int B, int G, int N) {
+  const int64_t nchunk = (N + CHAN_CHUNK - 1) / CHAN_CHUNK;
+  return nchunk > 1 ? (int64_t)B * G * nchunk * 1024 : 0;
+}
+
+int mmskin_channel_attention_forward(const float* q, const float* k, const float* v, float* x, float* attn, float* scratch, int B, int G,
+                                     int N, int Dh, int64_t q_tok, int64_t q_b, int64_t o_tok, int64_t o_b, float scale, void* stream) {
   ARG_CHECK(q && k && v && x, "channel_attention_forward: null argument");
   ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)x) & 15) == 0, "channel_attention_forward: 16-byte aligned tensors required");
   ChanArgs a;
   int rc = chan_args(a, B, G, N, Dh, q_tok, q_b, o_tok, o_b, scale, "channel_attention_forward");
   if (rc) return rc;
-  hipLaunchKernelGGL(channel_attn_fwd_kernel, dim3(B * G), dim3(256), 0, ST(stream), q, k, v, x, attn, a);
+  ARG_CHECK(a.nchunk == 1 || scratch, "channel_attention_forward: scratch required for N > %d", CHAN_CHUNK);
+  if (a.nchunk > 1) hipLaunchKernelGGL(chan_outer_kernel, dim3(B * G, a.nchunk), dim3(256), 0, ST(stream), q, q_tok, q_b, k, q_tok, q_b, scratch, G, N, a.nchunk);
+  hipLaunchKernelGGL(channel_attn_fwd_kernel, dim3(B * G, a.nchunk), dim3(256), 0, ST(stream), q, k, v, x, attn, scratch, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
 
 int mmskin_channel_attention_backward(const float* dO, const float* q, const float* k, const float* v, const float* attn, float* dq,
-                                      float* dk, float* dv, int B, int G, int N, int Dh, int64_t q_tok, int64_t q_b, int64_t o_tok,
-                                      int64_t o_b, float scale, void* stream) {
+                                      float* dk, float* dv, float* scratch, int B, int G, int N, int Dh, int64_t q_tok, int64_t q_b,
+                                      int64_t o_tok, int64_t o_b, float scale, void* stream) {
   ARG_CHECK(dO && q && k && v && attn && dq && dk && dv, "channel_attention_backward: null argument");
   ARG_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dO | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)attn) & 15) == 0,
             "channel_attention_backward: 16-byte aligned tensors required");
   ChanArgs a;
   int rc = chan_args(a, B, G, N, Dh, q_tok, q_b, o_tok, o_b, scale, "channel_attention_backward");
   if (rc) return rc;
-  hipLaunchKernelGGL(channel_attn_bwd_kernel, dim3(B * G), dim3(256), 0, ST(stream), dO, q, k, v, attn, dq, dk, dv, a);
+  ARG_CHECK(a.nchunk == 1 || scratch, "channel_attention_backward: scratch required for N > %d", CHAN_CHUNK);
+  if (a.nchunk > 1) hipLaunchKernelGGL(chan_outer_kernel, dim3(B * G, a.nchunk), dim3(256), 0, ST(stream), dO, o_tok, o_b, v, q_tok, q_b, scratch, G, N, a.nchunk);
+  hipLaunchKernelGGL(channel_attn_bwd_kernel, dim3(B * G, a.nchunk), dim3(256), 0, ST(stream), dO, q, k, v, attn, dq, dk, dv, scratch, a);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -106,8 +106,9 @@ _SIGNATURES = {
     "mmskin_attention_rows_backward": (_i, [_P] * 9 + [_i] * 4 + [_P, _P, _f, _f, _u64, _u64, _P]),
     "mmskin_window_attention_forward": (_i, [_P] * 5 + [_i] * 6 + [_i64] * 4 + [_f, _f, _u64, _u64, _P]),
     "mmskin_window_attention_backward": (_i, [_P] * 9 + [_i] * 6 + [_i64] * 4 + [_f, _f, _u64, _u64, _P]),
-    "mmskin_channel_attention_forward": (_i, [_P] * 5 + [_i] * 4 + [_i64] * 4 + [_f, _P]),
-    "mmskin_channel_attention_backward": (_i, [_P] * 8 + [_i] * 4 + [_i64] * 4 + [_f, _P]),
+    "mmskin_channel_attention_scratch_floats": (_i64, [_i, _i, _i]),
+    "mmskin_channel_attention_forward": (_i, [_P] * 6 + [_i] * 4 + [_i64] * 4 + [_f, _P]),
+    "mmskin_channel_attention_backward": (_i, [_P] * 9 + [_i] * 4 + [_i64] * 4 + [_f, _P]),
     "mmskin_linear_lane": (_i, [_P, _i, _P, _i, _P, _P, _P, _f, _u64, _u64, _P, _i, _i, _i, _i, _i, _P]),
     "mmskin_layernorm_forward_mixed": (_i, [_P] * 5 + [_i, _i, _f, _P]),
     "mmskin_flash_attention_forward": (_i, [_P] * 7 + [_i] * 4 + [_P, _i, _f, _i, _f, _u64, _u64, _P]),

@@ -512,8 +512,10 @@ class ChannelAttentionFn(torch.autograd.Function):
         step = G * Dh * 4
         base = qkv.data_ptr()
         ctx.scale = float(scale)
+        ns = _lib.load().mmskin_channel_attention_scratch_floats(B, G, N)
+        scratch = torch.empty(ns, device=qkv.device, dtype=torch.float32) if ns else None
         call("mmskin_channel_attention_forward", ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step), ptr(x),
-             ptr(attn), B, G, N, Dh, 3 * G * Dh, N * 3 * G * Dh, G * Dh, N * G * Dh, ctx.scale, stream())
+             ptr(attn), ptr(scratch) if scratch is not None else None, B, G, N, Dh, 3 * G * Dh, N * 3 * G * Dh, G * Dh, N * G * Dh, ctx.scale, stream())
         ctx.save_for_backward(qkv, attn)
         return x
 
@@ -526,8 +528,11 @@ class ChannelAttentionFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         step = G * Dh * 4
         base, dbase = qkv.data_ptr(), dqkv.data_ptr()
+        ns = _lib.load().mmskin_channel_attention_scratch_floats(B, G, N)
+        scratch = torch.empty(ns, device=qkv.device, dtype=torch.float32) if ns else None
         call("mmskin_channel_attention_backward", ptr(dO), ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step),
-             ptr(attn), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + step), ctypes.c_void_p(dbase + 2 * step), B, G, N, Dh,
+             ptr(attn), ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + step), ctypes.c_void_p(dbase + 2 * step),
+             ptr(scratch) if scratch is not None else None, B, G, N, Dh,
              3 * G * Dh, N * 3 * G * Dh, G * Dh, N * G * Dh, ctx.scale, stream())
         return dqkv, None
 

@@ -104,7 +104,7 @@ def _channel_reference(qkv, scale):
     return x.permute(0, 2, 1, 3)                                               # [B, N, G, Dh]
 
 
-@pytest.mark.parametrize("B,N,G", [(2, 49, 3), (1, 196, 12), (3, 7, 1), (2, 3136, 3), (1, 1, 2), (2, 50, 24)])
+@pytest.mark.parametrize("B,N,G", [(2, 49, 3), (1, 196, 12), (3, 7, 1), (2, 3136, 3), (1, 1, 2), (2, 50, 24), (1, 300, 2), (2, 257, 1), (1, 512, 3)])
 def test_channel_attention_token_major(B, N, G):
     """timm davit.py ChannelAttention.forward (dynamic_scale: q * N^-0.5) on the packed [B, N, 3, G, 32] qkv, against the same math in
     fp64 with explicit permutes: output, and d(qkv) through softmax and both products.  Odd token counts (the MFMA walks token pairs)."""
