@@ -296,6 +296,13 @@ int64_t mmskin_dwconv3_scratch_floats(int N, int H, int W, int C);
 int mmskin_dwconv3_forward(const float* x, const float* w, float* w_stage, float* y, int N, int H, int W, int C, void* stream);
 int mmskin_dwconv3_backward(const float* dy, const float* x, const float* w, float* w_stage, float* scratch, float* dx, float* dw,
                             int N, int H, int W, int C, void* stream);
+/* DaViT's convolutional position encoding (timm davit.py ConvPosEnc.forward: x + proj(x), proj = depthwise 3x3 with bias) in one pass each
+ * way: y = x + dwconv3(x, w) + b; backward dx = dy + dgrad(dy), dw, db = sum(dy) (from the weight-gradient pass: db needs dw).
+ * Staging / scratch as mmskin_dwconv3_*. */
+int mmskin_conv_pos_enc_forward(const float* x, const float* w, const float* b, float* w_stage, float* y, int N, int H, int W, int C,
+                                void* stream);
+int mmskin_conv_pos_enc_backward(const float* dy, const float* x, const float* w, float* w_stage, float* scratch, float* dx, float* dw,
+                                 float* db, int N, int H, int W, int C, void* stream);
 /* embedding gather for categorical metadata columns: table [ncols, card, E]; ids [B, ncols] int64 */
 int mmskin_embedding_forward(const float* table, const int64_t* ids, float* out, int B, int ncols, int card, int E,
                              void* stream);

@@ -416,4 +416,27 @@ int mmskin_dwconv3_backward(const float* dy, const float* x, const float* w, flo
   return MMSKIN_OK;
 }
 
+/* DaViT's convolutional position encoding in one pass each way (timm davit.py ConvPosEnc.forward: x + proj(x), proj = depthwise 3x3 with
+ * bias; loadImageModelClassifier.py:117-131):  y = x + dwconv3(x, w) + b.  Backward: dx = dy + dgrad(dy), dw, and db = sum(dy) from the
+ * weight-gradient pass.  Same staging / scratch as mmskin_dwconv3_*. */
+int mmskin_conv_pos_enc_forward(const float* x, const float* w, const float* b, float* w_stage, float* y, int N, int H, int W, int C,
+                                void* stream) {
+  ARG_CHECK(x && w && w_stage && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "conv_pos_enc_forward: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dw_stage_weights<float>(w, C, C, w_stage, st, 3);
+  if (rc) return rc;
+  return dwconv3_fwd<float>(x, w_stage, N, H, W, C, 1, y, st, 3, b, true);
+}
+int mmskin_conv_pos_enc_backward(const float* dy, const float* x, const float* w, float* w_stage, float* scratch, float* dx, float* dw,
+                                 float* db, int N, int H, int W, int C, void* stream) {
+  ARG_CHECK(dy && x && w && w_stage && scratch && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "conv_pos_enc_backward: bad argument");
+  ARG_CHECK(dw || !db, "conv_pos_enc_backward: db is produced by the weight-gradient pass (dw required)");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = dw_stage_weights<float>(w, C, C, w_stage, st, 3);
+  if (rc) return rc;
+  if (dx && (rc = dwconv3_dgrad<float>(dy, w_stage, N, H, W, C, 1, dx, st, 3, true))) return rc;
+  if (dw && (rc = dwconv3_wgrad<float>(dy, x, N, H, W, C, 1, scratch, dw, C, st, 3, db))) return rc;
+  return MMSKIN_OK;
+}
+
 }  // extern "C"

@@ -166,15 +166,17 @@ int gap_relu_bn_grad(const float* dfeat, const T* y, const float* scale, int N, 
 template <typename T>
 int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st, int ksize = 3);
 template <typename T>
-int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize = 3);
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize = 3,
+                const float* bias = nullptr, bool residual = false);   // residual (stride 1): out = in + conv(in) + bias
 template <typename T>
-int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize = 3);
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize = 3,
+                  bool residual = false);                              // residual: din = dout + dgrad(dout)
 // dw[c][tap] (OIHW [C][1][3][3], first Cv channels written) = sum over output pixels of dout * shifted input;
 // partial: scratch of dwconv3_wgrad_partial_floats() floats
 size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride, int ksize = 3);
 template <typename T>
 int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
-                  int Cv, hipStream_t st, int ksize = 3);
+                  int Cv, hipStream_t st, int ksize = 3, float* db = nullptr);   // db (3x3 / stride 1): sum of dout per channel, same pass
 
 // ---- squeeze-excitation and stochastic depth (EfficientNet MBConv)
 // y[n][hw][c] = x[n][hw][c] * gate[n][c]

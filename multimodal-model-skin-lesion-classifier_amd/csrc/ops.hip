@@ -1603,7 +1603,7 @@ int dw_stage_weights(const float* w_oihw, int C, int Cp, T* w_tc, hipStream_t st
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restrict__ in, const T* __restrict__ w, int H, int W,
                                                               int CPR, int stride, int K, int OH, int OW, T* __restrict__ out,
-                                                              size_t nchunks) {
+                                                              size_t nchunks, const float* __restrict__ bias, int residual) {
   constexpr int EPC = DT<T>::EPC;
   const size_t C = (size_t)CPR * EPC;
   const int pad = K / 2;
@@ -1629,6 +1629,16 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restri
         for (int e = 0; e < EPC; ++e) acc[e] += v.v[e] * wv.v[e];
       }
     }
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += bias[(size_t)cc * EPC + e];
+    }
+    if (residual) {   // y = x + conv(x) + b (stride 1: output pixel = input pixel)
+      Chunk<T> v;
+      v.load(in + i * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += v.v[e];
+    }
     Chunk<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
@@ -1636,13 +1646,16 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_fwd_kernel(const T* __restri
   }
 }
 template <typename T>
-int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize) {
+int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stride, T* out, hipStream_t st, int ksize, const float* bias,
+                bool residual) {
   constexpr int EPC = DT<T>::EPC;
   ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_fwd: C=%d stride=%d k=%d", C, stride, ksize);
   const int pad = ksize / 2;
   const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
   const size_t nch = (size_t)N * OH * OW * (C / EPC);
-  hipLaunchKernelGGL(dwconv3_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, in, w_tc, H, W, C / EPC, stride, ksize, OH, OW, out, nch);
+  ARG_CHECK(!residual || stride == 1, "dwconv_fwd: the residual form needs stride 1");
+  hipLaunchKernelGGL(dwconv3_fwd_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, in, w_tc, H, W, C / EPC, stride, ksize, OH, OW, out, nch,
+                     bias, residual ? 1 : 0);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1650,7 +1663,7 @@ int dwconv3_fwd(const T* in, const T* w_tc, int N, int H, int W, int C, int stri
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __restrict__ dout, const T* __restrict__ w, int H, int W,
                                                                 int CPR, int stride, int K, int OH, int OW, T* __restrict__ din,
-                                                                size_t nchunks) {
+                                                                size_t nchunks, int residual) {
   constexpr int EPC = DT<T>::EPC;
   const size_t C = (size_t)CPR * EPC;
   const int pad = K / 2;
@@ -1680,6 +1693,12 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __rest
         for (int e = 0; e < EPC; ++e) acc[e] += g.v[e] * wv.v[e];
       }
     }
+    if (residual) {   // d/dx of x + conv(x): the gradient passes through as well
+      Chunk<T> g;
+      g.load(dout + i * EPC);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) acc[e] += g.v[e];
+    }
     Chunk<T> o;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) o.v[e] = acc[e];
@@ -1687,13 +1706,15 @@ __global__ __launch_bounds__(EW_BLOCK) void dwconv3_dgrad_kernel(const T* __rest
   }
 }
 template <typename T>
-int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize) {
+int dwconv3_dgrad(const T* dout, const T* w_tc, int N, int H, int W, int C, int stride, T* din, hipStream_t st, int ksize, bool residual) {
   constexpr int EPC = DT<T>::EPC;
   ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_dgrad: C=%d stride=%d k=%d", C, stride, ksize);
   const int pad = ksize / 2;
   const int OH = (H + 2 * pad - ksize) / stride + 1, OW = (W + 2 * pad - ksize) / stride + 1;
   const size_t nch = (size_t)N * H * W * (C / EPC);
-  hipLaunchKernelGGL(dwconv3_dgrad_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dout, w_tc, H, W, C / EPC, stride, ksize, OH, OW, din, nch);
+  ARG_CHECK(!residual || stride == 1, "dwconv_dgrad: the residual form needs stride 1");
+  hipLaunchKernelGGL(dwconv3_dgrad_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dout, w_tc, H, W, C / EPC, stride, ksize, OH, OW, din, nch,
+                     residual ? 1 : 0);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1735,22 +1756,23 @@ size_t dwconv3_wgrad_partial_floats(int N, int H, int W, int C, int stride, int 
     for (int epc = 4; epc <= 8; epc *= 2)
       if (C % epc == 0) { const size_t nb = (size_t)dww_rows_plan(N, H, C / epc).nb; if (nb > strips) strips = nb; }
   }
-  return strips * ksize * ksize * C;
+  return strips * (ksize * ksize + 1) * C;    // + one row per strip for the bias gradient of the fused position-encoding form
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_wgrad_rows_kernel(const T* __restrict__ dout, const T* __restrict__ in, int H, int W,
                                                                 int CPR, int CW, int lanes, int rpl, int NR,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, int with_bias) {
   constexpr int EPC = DT<T>::EPC;
   extern __shared__ float dww_red[];          // [lanes][CW * EPC]
   const int cx = threadIdx.x % CW, ly = threadIdx.x / CW;
   const int cc = blockIdx.y * CW + cx;
   const size_t C = (size_t)CPR * EPC;
-  float acc[9][EPC];
+  float acc[10][EPC];                         // 9 taps + sum of dY (bias gradient)
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 10; ++t)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) acc[t][e] = 0.f;
+  const int NT = with_bias ? 10 : 9;
   if (ly < lanes && cc < CPR) {
     for (int k = 0; k < rpl; ++k) {
       const int row = (blockIdx.x * rpl + k) * lanes + ly;      // = n * H + oy (stride 1, pad 1: the output has the input's geometry)
@@ -1790,11 +1812,15 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_rows_kernel(const T* __rest
             acc[r * 3 + 2][e] += g.v[e] * c[r].v[e];
           }
 #pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[9][e] += g.v[e];
+#pragma unroll
         for (int r = 0; r < 3; ++r) { a[r] = b[r]; b[r] = c[r]; }
       }
     }
   }
-  for (int t = 0; t < 9; ++t) {               // reduce the row lanes, one tap at a time
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {              // reduce the row lanes, one tap at a time
+    if (t >= NT) break;
     if (ly < lanes) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) dww_red[ly * CW * EPC + cx * EPC + e] = acc[t][e];
@@ -1805,7 +1831,7 @@ __global__ __launch_bounds__(256) void dwconv3_wgrad_rows_kernel(const T* __rest
       if (ch < (int)C) {
         float s2 = 0.f;
         for (int l = 0; l < lanes; ++l) s2 += dww_red[l * CW * EPC + i];
-        partial[((size_t)blockIdx.x * 9 + t) * C + ch] = s2;
+        partial[((size_t)blockIdx.x * NT + t) * C + ch] = s2;
       }
     }
     __syncthreads();
@@ -1875,27 +1901,31 @@ __global__ void dwconv3_wgrad_finalize_kernel(const float* __restrict__ partial,
   if (c < Cv) dw[(size_t)c * KK + t] = (float)s;
 }
 // the same sum with 16 strip lanes per (tap, channel) column: the row-walking kernel leaves a few hundred partial rows
+// NT = KK (+ 1: the last row of a strip is the bias gradient -> db)
 __global__ __launch_bounds__(1024) void dwconv3_wgrad_finalize_lanes_kernel(const float* __restrict__ partial, int nstrips, int C, int Cv,
-                                                                            int KK, float* __restrict__ dw) {
+                                                                            int KK, int NT, float* __restrict__ dw, float* __restrict__ db) {
   __shared__ double red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + cx;   // over KK * C: (tap, c)
+  const int i = blockIdx.x * 64 + cx;   // over NT * C: (tap, c)
   double s = 0.0;
-  if (i < KK * C)
-    for (int k = ry; k < nstrips; k += 16) s += (double)partial[(size_t)k * KK * C + i];
+  if (i < NT * C)
+    for (int k = ry; k < nstrips; k += 16) s += (double)partial[(size_t)k * NT * C + i];
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && i < KK * C) {
+  if (ry == 0 && i < NT * C) {
     double t = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k][cx];
     const int tp = i / C, c = i - tp * C;
-    if (c < Cv) dw[(size_t)c * KK + tp] = (float)t;
+    if (c < Cv) {
+      if (tp < KK) dw[(size_t)c * KK + tp] = (float)t;
+      else if (db) db[c] = (float)t;
+    }
   }
 }
 template <typename T>
 int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int stride, float* partial, float* dw,
-                  int Cv, hipStream_t st, int ksize) {
+                  int Cv, hipStream_t st, int ksize, float* db) {
   constexpr int EPC = DT<T>::EPC;
   ARG_CHECK(C % EPC == 0 && (stride == 1 || stride == 2) && (ksize == 3 || ksize == 5), "dwconv_wgrad: C=%d stride=%d k=%d", C, stride, ksize);
   const int pad = ksize / 2;
@@ -1905,11 +1935,13 @@ int dwconv3_wgrad(const T* dout, const T* in, int N, int H, int W, int C, int st
   const size_t per = (opix + strips - 1) / strips;
   const int CPR = C / EPC, KK = ksize * ksize;
   static const bool rows_on = [] { const char* v = getenv("MMSKIN_DWW_ROWS"); return !v || atoi(v) != 0; }();
-  if (rows_on && stride == 1 && ksize == 3) {
+  ARG_CHECK(!db || (stride == 1 && ksize == 3), "dwconv_wgrad: the bias gradient comes with the 3x3 / stride 1 kernel only");
+  if ((rows_on || db) && stride == 1 && ksize == 3) {
     const DwwRowsPlan g = dww_rows_plan(N, H, CPR);
+    const int NT = db ? 10 : 9;
     hipLaunchKernelGGL(dwconv3_wgrad_rows_kernel<T>, dim3(g.nb, g.gy), dim3(256), (size_t)g.lanes * g.CW * EPC * sizeof(float), st, dout, in,
-                       H, W, CPR, g.CW, g.lanes, g.rpl, N * H, partial);
-    hipLaunchKernelGGL(dwconv3_wgrad_finalize_lanes_kernel, dim3(ceil_div(KK * C, 64)), dim3(1024), 0, st, partial, g.nb, C, Cv, KK, dw);
+                       H, W, CPR, g.CW, g.lanes, g.rpl, N * H, partial, db ? 1 : 0);
+    hipLaunchKernelGGL(dwconv3_wgrad_finalize_lanes_kernel, dim3(ceil_div(NT * C, 64)), dim3(1024), 0, st, partial, g.nb, C, Cv, KK, NT, dw, db);
     HIP_CHECK_RET(hipGetLastError());
     return MMSKIN_OK;
   }
@@ -2141,9 +2173,9 @@ int ew_add(const T* a, const T* b, T* out, size_t n, hipStream_t st) {
 
 #define INST_DW(T)                                                                                        \
   template int dw_stage_weights<T>(const float*, int, int, T*, hipStream_t, int);                         \
-  template int dwconv3_fwd<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int);         \
-  template int dwconv3_dgrad<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int);       \
-  template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t, int); \
+  template int dwconv3_fwd<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int, const float*, bool); \
+  template int dwconv3_dgrad<T>(const T*, const T*, int, int, int, int, int, T*, hipStream_t, int, bool); \
+  template int dwconv3_wgrad<T>(const T*, const T*, int, int, int, int, int, float*, float*, int, hipStream_t, int, float*); \
   template int se_scale_fwd<T>(const T*, const float*, int, int, int, T*, hipStream_t);                   \
   template int se_dgate<T>(const T*, const T*, int, int, int, float*, hipStream_t);                       \
   template int gap_reduce<T>(const T*, const T*, int, int, int, float, float*, hipStream_t);              \

@@ -89,6 +89,8 @@ _SIGNATURES = {
     "mmskin_dwconv3_scratch_floats": (_i64, [_i, _i, _i, _i]),
     "mmskin_dwconv3_forward": (_i, [_P] * 4 + [_i] * 4 + [_P]),
     "mmskin_dwconv3_backward": (_i, [_P] * 7 + [_i] * 4 + [_P]),
+    "mmskin_conv_pos_enc_forward": (_i, [_P] * 5 + [_i] * 4 + [_P]),
+    "mmskin_conv_pos_enc_backward": (_i, [_P] * 8 + [_i] * 4 + [_P]),
     "mmskin_scale_add_forward": (_i, [_P] * 4 + [_i64, _i, _P]),
     "mmskin_scale_mul": (_i, [_P] * 3 + [_i64, _i, _i, _P]),
     "mmskin_token_mean_forward": (_i, [_P, _P, _i, _i, _i, _i, _P]),

@@ -950,6 +950,40 @@ dwconv3 = DwConv3Fn.apply
 
 
 @no_second_order
+class ConvPosEncFn(torch.autograd.Function):
+    """x + dwconv3(x, w) + b on NHWC fp32 (timm davit.py ConvPosEnc.forward) in one kernel; the backward's dx = dy + dgrad(dy) in one
+    kernel and dw, db from one pass over dy."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_gpu(x, "conv_pos_enc")
+        x, w, b = _f32c(x), _f32c(w), _f32c(b)
+        N, H, W, C = x.shape
+        y = torch.empty_like(x)
+        stage = torch.empty(9 * C, device=x.device, dtype=torch.float32)
+        call("mmskin_conv_pos_enc_forward", ptr(x), ptr(w), ptr(b), ptr(stage), ptr(y), N, H, W, C, stream())
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, H, W, C = x.shape
+        dy = _f32c(dy)
+        stage = torch.empty(9 * C, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(_lib.load().mmskin_dwconv3_scratch_floats(N, H, W, C), device=x.device, dtype=torch.float32)
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty(C, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        call("mmskin_conv_pos_enc_backward", ptr(dy), ptr(x), ptr(w), ptr(stage), ptr(scratch), ptr(dx), ptr(dw), ptr(db), N, H, W, C, stream())
+        return dx, (dw if ctx.needs_input_grad[1] else None), db
+
+
+conv_pos_enc = ConvPosEncFn.apply
+
+
+@no_second_order
 class GeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -43,6 +43,8 @@ class _ConvPosEnc(nn.Module):
         self.proj = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)
 
     def forward(self, x):             # x [B, H, W, C] -> x + dwconv(x) + bias
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0:
+            return ops.conv_pos_enc(x, self.proj.weight, self.proj.bias)      # one kernel; bias gradient from the weight-gradient pass
         return ops.add(ops.add(x, ops.dwconv3(x, self.proj.weight)), self.proj.bias)
 
 

@@ -120,3 +120,18 @@ def test_channel_attention_token_major(B, N, G):
     x = ops.channel_attention(dev, scale)
     x.backward(dO.to(DEV))
     _chk(x, x_ref); _chk(dev.grad, ref_in.grad, 2e-4)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 96), (1, 56, 56, 96), (3, 7, 5, 192), (2, 2, 3, 768)])
+def test_conv_pos_enc_fused(N, H, W, C):
+    """x + dwconv3(x, w) + b (timm davit.py ConvPosEnc) as one op: output, dx (gradient through both branches), dw and db."""
+    g = torch.Generator().manual_seed(N + H * 3 + C)
+    x = torch.randn(N, H, W, C, generator=g); w = torch.randn(C, 1, 3, 3, generator=g) * 0.3; b = torch.randn(C, generator=g)
+    dy = torch.randn(N, H, W, C, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    y_ref = xr + F.conv2d(xr.permute(0, 3, 1, 2), wr, br, padding=1, groups=C).permute(0, 2, 3, 1)
+    y_ref.backward(dy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.conv_pos_enc(xd, wd, bd)
+    y.backward(dy.to(DEV))
+    _chk(y, y_ref); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad, 2e-4); _chk(bd.grad, br.grad, 2e-4)
