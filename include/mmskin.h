@@ -146,6 +146,11 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
  * null.  dy_scratch[M,N] is required when y_relu is given (holds the masked dy). */
 int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
                            float* dx, float* dw, float* db, int M, int K, int N, void* stream);
+/* Backward of h = gelu(x w^T + b) (nn.Linear -> nn.GELU, the first half of timm's Mlp) from dh and the saved pre-activation z [M][N]:
+ * gelu'(z) is applied inside the pass that converts the gradient to bf16 for the dgrad / wgrad GEMMs and sums it for db, so the fp32
+ * gradient of the pre-activation is never written.  dy_scratch [M][N] is used only off the bf16-operand large-GEMM path. */
+int mmskin_linear_gelu_backward(const float* dh, const float* x, const float* w, const float* z, float* dy_scratch, float* dx, float* dw,
+                                float* db, int M, int K, int N, void* stream);
 /* y = LN(x)*g + b over the last dim, optional fused ReLU; mean/rstd [M] saved for backward */
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                              int M, int N, float eps, int relu, void* stream);

@@ -429,9 +429,15 @@ static int rows_sum(const float* part, int R, int ncols, int split, float* out0,
 // Column sums with float4 loads: CW chunk columns x (256 / CW) row lanes per block, two rows in flight per lane, one partial row
 // per block, rows_sum adds the blocks.  CVT: the same pass also writes the bf16 copy (row pitch cols_pad, zero pad columns) a
 // bf16-operand GEMM consumes -- Linear backward needs both from dy (bias gradient and the dgrad / wgrad operand), so dy is read once.
-template <bool CVT>
+// GELU: x is the gradient w.r.t. gelu(z); it is multiplied by gelu'(z) on the way in (the exact-erf GELU of nn.GELU), so a Linear ->
+// GELU pair's backward reads dy and z once and never writes the fp32 gradient of the pre-activation.
+__device__ __forceinline__ float gelu_grad(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+template <bool CVT, bool GELU = false>
 __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ x, int64_t M, int N, int rows_per_block, int CW, int lanes,
-                                                      float* __restrict__ part, bf16_t* __restrict__ out16, int cols_pad) {
+                                                      float* __restrict__ part, bf16_t* __restrict__ out16, int cols_pad,
+                                                      const float* __restrict__ zg = nullptr) {
   extern __shared__ float cs_red[];           // [lanes][CW * 4]
   const int cx = threadIdx.x % CW, ly = threadIdx.x / CW;
   const int c4 = blockIdx.y * CW + cx, col = c4 * 4;
@@ -445,6 +451,11 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     for (; r + lanes < r1; r += 2 * lanes) {
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
       if (real) { v0 = *reinterpret_cast<const float4*>(x + r * N + col); v1 = *reinterpret_cast<const float4*>(x + (r + lanes) * N + col); }
+      if (GELU && real) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zg + r * N + col), z1 = *reinterpret_cast<const float4*>(zg + (r + lanes) * N + col);
+        v0.x *= gelu_grad(z0.x); v0.y *= gelu_grad(z0.y); v0.z *= gelu_grad(z0.z); v0.w *= gelu_grad(z0.w);
+        v1.x *= gelu_grad(z1.x); v1.y *= gelu_grad(z1.y); v1.z *= gelu_grad(z1.z); v1.w *= gelu_grad(z1.w);
+      }
       a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
       a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
       if (CVT) {
@@ -455,6 +466,10 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ 
     if (r < r1) {
       float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (real) v0 = *reinterpret_cast<const float4*>(x + r * N + col);
+      if (GELU && real) {
+        const float4 z0 = *reinterpret_cast<const float4*>(zg + r * N + col);
+        v0.x *= gelu_grad(z0.x); v0.y *= gelu_grad(z0.y); v0.z *= gelu_grad(z0.z); v0.w *= gelu_grad(z0.w);
+      }
       a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
       if (CVT) *reinterpret_cast<uint2*>(out16 + r * cols_pad + col) = make_uint2(f32_to_bf16_bits(v0.x) | (f32_to_bf16_bits(v0.y) << 16), f32_to_bf16_bits(v0.z) | (f32_to_bf16_bits(v0.w) << 16));
     }
@@ -487,10 +502,12 @@ static inline Colsum4Plan colsum4_plan(int64_t M, int ncol4) {
 }
 static inline size_t colsum4_part_bytes(int N) { return (size_t)1024 * N * sizeof(float); }
 // out[N] = column sums of x [M][N]; out16 != null: also the bf16 copy [M][cols_pad].  part: colsum4_part_bytes(N) of scratch.
-static int colsum4(const float* x, float* out, int64_t M, int N, float* part, bf16_t* out16, int cols_pad, hipStream_t st) {
+static int colsum4(const float* x, float* out, int64_t M, int N, float* part, bf16_t* out16, int cols_pad, hipStream_t st,
+                   const float* z_gelu = nullptr) {
   const Colsum4Plan g = colsum4_plan(M, (out16 ? cols_pad : N) / 4);
   const size_t lds = (size_t)g.lanes * g.CW * 4 * sizeof(float);
-  if (out16) hipLaunchKernelGGL(colsum4_kernel<true>, dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad);
+  if (out16 && z_gelu) hipLaunchKernelGGL((colsum4_kernel<true, true>), dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad, z_gelu);
+  else if (out16) hipLaunchKernelGGL(colsum4_kernel<true>, dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad);
   else hipLaunchKernelGGL(colsum4_kernel<false>, dim3(g.nbx, g.gy), dim3(256), lds, st, x, M, N, g.rpb, g.CW, g.lanes, part, out16, cols_pad);
   HIP_CHECK_RET(hipGetLastError());
   return rows_sum(part, g.nbx, N, N, out, nullptr, st);
@@ -1435,11 +1452,19 @@ int mmskin_linear_lane(const void* x, int x_dtype, const void* w, int w_dtype, c
   return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, st, (b || act || y_dtype == 0 || tr) ? &f : nullptr);
 }
 
-int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
-                           float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
+static int linear_backward_impl(const float* dy, const float* x, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
+                                float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
   ARG_CHECK(dy && M > 0 && K > 0 && N > 0, "linear_backward: bad argument");
+  ARG_CHECK(!(y_relu && z_gelu), "linear_backward: one activation");
   hipStream_t st = ST(stream);
   const float* g = dy;
+  const bool bf16_gemm = linear_bf16() && (linear_big_padded(M, K, N) || linear_big(M, K, N));
+  if (z_gelu && !bf16_gemm) {   // no conversion pass to fold the GELU derivative into: its own pass
+    ARG_CHECK(dy_scratch, "linear_backward: dy_scratch required with z_gelu");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, dy, z_gelu, dy_scratch, (int64_t)M * N);
+    HIP_CHECK_RET(hipGetLastError());
+    g = dy_scratch; z_gelu = nullptr;
+  }
   if (y_relu) {
     ARG_CHECK(dy_scratch, "linear_backward: dy_scratch required with y_relu");
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, dy, y_relu, dy_scratch, (int64_t)M * N);
@@ -1456,8 +1481,8 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
     bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
     float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
-    if (db) {   // bias gradient from the pass that converts dy
-      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, Np, st))) return rc;
+    if (db || z_gelu) {   // bias gradient (and the GELU derivative) from the pass that converts dy
+      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, Np, st, z_gelu))) return rc;
       db = nullptr;
     } else if ((rc = cvt_to_bf16_pad(g, g16, M, N, M, Np, st))) return rc;
     if (dx) {
@@ -1484,8 +1509,8 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     if (!sc) { mmskin_set_error("linear_backward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
     bf16_t* g16 = reinterpret_cast<bf16_t*>(sc); bf16_t* t16 = reinterpret_cast<bf16_t*>(sc + gb); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + gb + xb);
     float* slab = reinterpret_cast<float*>(sc + gb + xb + wb);
-    if (db) {   // bias gradient from the pass that converts dy
-      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, N, st))) return rc;
+    if (db || z_gelu) {   // bias gradient (and the GELU derivative) from the pass that converts dy
+      if ((rc = colsum4(g, db, M, N, reinterpret_cast<float*>(sc + gb + xb + wb + slb), g16, N, st, z_gelu))) return rc;
       db = nullptr;
     } else if ((rc = cvt_to_bf16(g, g16, (int64_t)M * N, st))) return rc;
     if (dx) {
@@ -1533,6 +1558,18 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
     if ((rc = colsum(g, db, M, N, st))) return rc;
   }
   return MMSKIN_OK;
+}
+
+int mmskin_linear_backward(const float* dy, const float* x, const float* w, const float* y_relu, float* dy_scratch,
+                           float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
+  return linear_backward_impl(dy, x, w, y_relu, nullptr, dy_scratch, dx, dw, db, M, K, N, stream);
+}
+// Backward of h = gelu(x w^T + b) given dh and the saved pre-activation z [M][N]: the GELU derivative is applied inside the pass that
+// converts the gradient for the bf16 GEMMs (and sums it for db), so d(z) never exists in fp32.  dy_scratch [M][N]: used off the bf16 path.
+int mmskin_linear_gelu_backward(const float* dh, const float* x, const float* w, const float* z, float* dy_scratch, float* dx, float* dw,
+                                float* db, int M, int K, int N, void* stream) {
+  ARG_CHECK(z, "linear_gelu_backward: z required");
+  return linear_backward_impl(dh, x, w, nullptr, z, dy_scratch, dx, dw, db, M, K, N, stream);
 }
 
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,

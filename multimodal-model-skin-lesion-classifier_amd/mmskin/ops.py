@@ -1006,11 +1006,52 @@ class GeluFn(torch.autograd.Function):
 gelu = GeluFn.apply
 
 
+@no_second_order
+class LinearGeluFn(torch.autograd.Function):
+    """h = gelu(x @ w.T + b) with gradients (first half of a transformer MLP).  Forward: Linear, then GELU (the pre-activation z is kept
+    for the backward); backward: ONE C call -- gelu'(z) is applied inside the pass that converts dh for the bf16 GEMMs and sums it for
+    db (mmskin_linear_gelu_backward), so d(z) is never written in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_gpu(x, "linear_gelu")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w = _f32c(w)
+        M, K = x2.shape
+        N = w.shape[0]
+        z = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(z), M, K, N, 0, stream())
+        h = torch.empty_like(z)
+        call("mmskin_gelu_forward", ptr(z), ptr(h), z.numel(), stream())
+        ctx.save_for_backward(x2, w, z)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return h.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dh):
+        x2, w, z = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dh2 = _f32c(dh).reshape(M, N)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_x else None
+        dw = torch.empty_like(w) if need_w else None
+        db = torch.empty(N, device=dh.device, dtype=torch.float32) if need_b else None
+        # off the bf16-operand large-GEMM path (head.hip: linear_big / linear_big_padded) the C side applies gelu'(z) in a pass of its own
+        fused = get_linear_dtype() == "bf16" and M >= 2048 and K % 8 == 0 and N % 8 == 0 and K >= 32 and N >= 32
+        scratch = None if fused else torch.empty_like(dh2)
+        call("mmskin_linear_gelu_backward", ptr(dh2), ptr(x2), ptr(w), ptr(z), ptr(scratch), ptr(dx), ptr(dw), ptr(db), M, K, N, stream())
+        return (dx.reshape(ctx.xshape) if need_x else None), dw, db
+
+
 def linear_gelu(x, w, b=None, out_dtype=None):
     """gelu(x @ w.T + b) -- the first half of a transformer MLP.  Without gradients (frozen encoders, inference) bias and the
     exact GELU run in the GEMM epilogue (one launch, the pre-activation never reaches memory); with gradients the two ops
     stay separate because GELU's backward needs the pre-activation."""
     if _needs_grad(x, w, b):
+        if x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
+            return LinearGeluFn.apply(x, w, b)
         return gelu(linear(x, w, b))
     if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
         return linear_lane(x, w, b, 2, out_dtype=out_dtype)

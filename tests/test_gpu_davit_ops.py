@@ -135,3 +135,31 @@ def test_conv_pos_enc_fused(N, H, W, C):
     y = ops.conv_pos_enc(xd, wd, bd)
     y.backward(dy.to(DEV))
     _chk(y, y_ref); _chk(xd.grad, xr.grad); _chk(wd.grad, wr.grad, 2e-4); _chk(bd.grad, br.grad, 2e-4)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,K,N", [(4096, 96, 384), (2304, 192, 768), (100, 64, 256)])
+def test_linear_gelu_backward_in_one_call(mode, M, K, N):
+    """gelu(x w^T + b) with gradients (timm Mlp.fc1 -> act): the backward applies gelu'(z) inside the dy conversion pass in bf16-operand
+    mode (padded 96-wide and 64-multiple shapes) and in a pass of its own otherwise.  Reference: F.gelu(F.linear) in fp64; tolerance
+    1e-4 of the maximum in fp32, 2e-2 relative L2 with bf16 operands."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g) * 0.1
+    dh = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    F.gelu(F.linear(xr, wr, br)).backward(dh.double())
+    prev = ops.get_linear_dtype()
+    ops.set_linear_dtype(mode)
+    try:
+        xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        h = ops.linear_gelu(xd, wd, bd)
+        h.backward(dh.to(DEV))
+    finally:
+        ops.set_linear_dtype(prev)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double()))
+    for got, want in ((h, ref), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        got, want = got.detach().cpu().double(), want.detach()
+        if mode == "fp32" or M < 2048:
+            assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+        else:   # bf16 operands: relative L2 of the whole tensor
+            assert ((got - want).norm() / want.norm()).item() < 2e-2
