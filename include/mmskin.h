@@ -151,6 +151,16 @@ int mmskin_linear_backward(const float* dy, const float* x, const float* w, cons
  * gradient of the pre-activation is never written.  dy_scratch [M][N] is used only off the bf16-operand large-GEMM path. */
 int mmskin_linear_gelu_backward(const float* dh, const float* x, const float* w, const float* z, float* dy_scratch, float* dx, float* dw,
                                 float* db, int M, int K, int N, void* stream);
+/* The bf16-operand large-GEMM path converts x to bf16 for the forward GEMM and again for the backward's weight-gradient GEMM.
+ * mmskin_linear_x16_pitch > 0 (the row pitch in elements; 0: this shape / mode makes no such copy) lets a caller keep the forward's
+ * copy instead: _forward_keep writes it to x16_keep [M][pitch] (bf16), _backward_keep takes it in x's place (y_relu / z_gelu: the saved
+ * output of a fused ReLU or pre-activation of a following GELU, at most one, as in mmskin_linear_backward / _gelu_backward).
+ * Same arithmetic as mmskin_linear_forward / _backward: the kept copy is the tensor the scratch conversion would have produced. */
+int mmskin_linear_x16_pitch(int M, int K, int N);
+int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, float* y, void* x16_keep, int M, int K, int N, int relu,
+                               void* stream);
+int mmskin_linear_backward_keep(const float* dy, const void* x16, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
+                                float* dx, float* dw, float* db, int M, int K, int N, void* stream);
 /* y = LN(x)*g + b over the last dim, optional fused ReLU; mean/rstd [M] saved for backward */
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                              int M, int N, float eps, int relu, void* stream);

@@ -1332,8 +1332,10 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
-int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
-                          void* stream) {
+// x16_keep (optional): the bf16 copy of x the GEMM consumes is written THERE ([M][mmskin_linear_x16_pitch]) instead of into library
+// scratch, so the caller can hand it back to the backward's weight-gradient GEMM (no second conversion of x, half the saved bytes).
+static int linear_forward_impl(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* x16_keep,
+                               void* stream) {
   ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
   ARG_CHECK(relu >= 0 && relu <= 2, "linear_forward: activation %d (0 none, 1 ReLU, 2 exact GELU)", relu);
   if (linear_bf16() && linear_big_padded(M, K, N)) {
@@ -1342,7 +1344,8 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
     const size_t xb = align_up((size_t)M * Kp * 2, 256), wb = align_up((size_t)Np * Kp * 2, 256), yb = align_up((size_t)M * Np * 2, 256);
     unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb + yb));
     if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
-    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
+    bf16_t* x16 = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+    bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
     int rc;
     if ((rc = cvt_to_bf16_pad(x, x16, M, K, M, Kp, ST(stream)))) return rc;
     if ((rc = cvt_to_bf16_pad(w, w16, N, K, Np, Kp, ST(stream)))) return rc;
@@ -1355,7 +1358,8 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
     const size_t xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
     unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb));
     if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
-    bf16_t* x16 = reinterpret_cast<bf16_t*>(sc); bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb);
+    bf16_t* x16 = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+    bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb);
     int rc;
     if ((rc = cvt_to_bf16(x, x16, (int64_t)M * K, ST(stream)))) return rc;
     if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, ST(stream)))) return rc;
@@ -1372,6 +1376,24 @@ int mmskin_linear_forward(const float* x, const float* w, const float* b, float*
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, ST(stream), y, y, (int64_t)M * N);   // in place: element i only
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
+}
+
+int mmskin_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu,
+                          void* stream) {
+  return linear_forward_impl(x, w, b, y, M, K, N, relu, nullptr, stream);
+}
+// Row pitch (elements) of the bf16 operand copy the current mode's large-GEMM path makes of an [M][K] input, 0 when this shape / mode
+// does not take that path (then there is nothing to keep).
+int mmskin_linear_x16_pitch(int M, int K, int N) {
+  if (!linear_bf16() || M <= 0 || K <= 0 || N <= 0) return 0;
+  if (linear_big_padded(M, K, N)) return pad64(K);
+  if (linear_big(M, K, N)) return K;
+  return 0;
+}
+int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, float* y, void* x16_keep, int M, int K, int N, int relu,
+                               void* stream) {
+  ARG_CHECK(x16_keep && mmskin_linear_x16_pitch(M, K, N) > 0, "linear_forward_keep: no bf16 operand copy for this shape / mode");
+  return linear_forward_impl(x, w, b, y, M, K, N, relu, x16_keep, stream);
 }
 
 // Linear with bf16 tensors at either end (the inference lane of the transformer encoders in bf16-operand mode): x and / or y may be
@@ -1453,12 +1475,13 @@ int mmskin_linear_lane(const void* x, int x_dtype, const void* w, int w_dtype, c
 }
 
 static int linear_backward_impl(const float* dy, const float* x, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
-                                float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
+                                float* dx, float* dw, float* db, int M, int K, int N, void* stream, const void* x16_kept = nullptr) {
   ARG_CHECK(dy && M > 0 && K > 0 && N > 0, "linear_backward: bad argument");
   ARG_CHECK(!(y_relu && z_gelu), "linear_backward: one activation");
   hipStream_t st = ST(stream);
   const float* g = dy;
   const bool bf16_gemm = linear_bf16() && (linear_big_padded(M, K, N) || linear_big(M, K, N));
+  ARG_CHECK(!x16_kept || bf16_gemm, "linear_backward: the kept bf16 operand belongs to the bf16 large-GEMM path (mode changed since the forward?)");
   if (z_gelu && !bf16_gemm) {   // no conversion pass to fold the GELU derivative into: its own pass
     ARG_CHECK(dy_scratch, "linear_backward: dy_scratch required with z_gelu");
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d((int64_t)M * N)), dim3(256), 0, st, dy, z_gelu, dy_scratch, (int64_t)M * N);
@@ -1494,9 +1517,10 @@ static int linear_backward_impl(const float* dy, const float* x, const float* w,
       if ((rc = unpad_bias_act(t16, nullptr, dx, M, K, Kp, 0, st))) return rc;
     }
     if (dw) {
-      ARG_CHECK(x, "linear_backward: x required for dw");
-      if ((rc = cvt_to_bf16_pad(x, t16, M, K, M, Kp, st))) return rc;
-      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, t16, slab, dw, st, N, K))) return rc;   // reduces straight into the unpadded [N][K] gradient
+      ARG_CHECK(x || x16_kept, "linear_backward: x required for dw");
+      const bf16_t* xo = reinterpret_cast<const bf16_t*>(x16_kept);
+      if (!xo) { if ((rc = cvt_to_bf16_pad(x, t16, M, K, M, Kp, st))) return rc; xo = t16; }
+      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, xo, slab, dw, st, N, K))) return rc;   // reduces straight into the unpadded [N][K] gradient
     }
     if (db && (rc = colsum(g, db, M, N, st))) return rc;
     return MMSKIN_OK;
@@ -1517,13 +1541,23 @@ static int linear_backward_impl(const float* dy, const float* x, const float* w,
       ARG_CHECK(w, "linear_backward: w required for dx");
       hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3(ceil_div(K, 32), ceil_div(N, 32)), dim3(32, 8), 0, st, w, w16, N, K);
       HIP_CHECK_RET(hipGetLastError());
-      if ((rc = launch_conv_dgrad<bf16_t>(s, g16, w16, t16, (const bf16_t*)nullptr, st))) return rc;   // dx in bf16, then widened
-      if ((rc = cvt_to_f32(t16, dx, (int64_t)M * K, st))) return rc;
+      // dx = g w as a FORWARD 1x1 conv over the transposed weight (w16 [K][N] is its [Cout][Cin] layout): the light epilogue writes
+      // fp32 straight into dx -- no bf16 round trip and widening pass (10 us x 57 per DaViT step)
+      static const bool dx_f32 = [] { const char* v = getenv("MMSKIN_LINEAR_DX_F32"); return !v || atoi(v) != 0; }();
+      if (dx_f32) {
+        ConvShape sd = {M, 1, 1, N, K, 1, 1, 1, 0};
+        FwdFuse f; f.out_f32 = dx;
+        if ((rc = launch_conv_fwd<bf16_t>(sd, g16, w16, reinterpret_cast<bf16_t*>(dx), nullptr, nullptr, st, &f))) return rc;
+      } else {
+        if ((rc = launch_conv_dgrad<bf16_t>(s, g16, w16, t16, (const bf16_t*)nullptr, st))) return rc;   // dx in bf16, then widened
+        if ((rc = cvt_to_f32(t16, dx, (int64_t)M * K, st))) return rc;
+      }
     }
     if (dw) {
-      ARG_CHECK(x, "linear_backward: x required for dw");
-      if ((rc = cvt_to_bf16(x, t16, (int64_t)M * K, st))) return rc;
-      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, t16, slab, dw, st))) return rc;
+      ARG_CHECK(x || x16_kept, "linear_backward: x required for dw");
+      const bf16_t* xo = reinterpret_cast<const bf16_t*>(x16_kept);
+      if (!xo) { if ((rc = cvt_to_bf16(x, t16, (int64_t)M * K, st))) return rc; xo = t16; }
+      if ((rc = launch_conv_wgrad<bf16_t>(s, g16, xo, slab, dw, st))) return rc;
     }
     if (db && (rc = colsum(g, db, M, N, st))) return rc;
     return MMSKIN_OK;
@@ -1570,6 +1604,13 @@ int mmskin_linear_gelu_backward(const float* dh, const float* x, const float* w,
                                 float* db, int M, int K, int N, void* stream) {
   ARG_CHECK(z, "linear_gelu_backward: z required");
   return linear_backward_impl(dh, x, w, nullptr, z, dy_scratch, dx, dw, db, M, K, N, stream);
+}
+// Backward with the bf16 operand copy kept by mmskin_linear_forward_keep in x's place (x16 [M][mmskin_linear_x16_pitch]); y_relu /
+// z_gelu as in the two entry points above (at most one).
+int mmskin_linear_backward_keep(const float* dy, const void* x16, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
+                                float* dx, float* dw, float* db, int M, int K, int N, void* stream) {
+  ARG_CHECK(x16, "linear_backward_keep: x16 required");
+  return linear_backward_impl(dy, nullptr, w, y_relu, z_gelu, dy_scratch, dx, dw, db, M, K, N, stream, x16);
 }
 
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,

@@ -28,7 +28,8 @@ def _f32c(t):
 
 @no_second_order
 class LinearFn(torch.autograd.Function):
-    """y = x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU])."""
+    """y = x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU]).  When the bf16-operand large-GEMM path runs and w trains, the bf16
+    copy of x the forward GEMM consumed is what is saved for the weight gradient (half the bytes, no second conversion)."""
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
@@ -38,25 +39,38 @@ class LinearFn(torch.autograd.Function):
         M, K = x2.shape
         N = w.shape[0]
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(y), M, K, N, int(relu), stream())
-        ctx.save_for_backward(x2, w, y if relu else None)
+        need_w = ctx.needs_input_grad[1]
+        pitch = _lib.load().mmskin_linear_x16_pitch(M, K, N) if need_w else 0
+        if pitch:
+            x16 = torch.empty((M, pitch), device=x.device, dtype=torch.bfloat16)
+            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), ptr(y), ptr(x16), M, K, N, int(relu), stream())
+            ctx.save_for_backward(x16, w, y if relu else None)
+        else:
+            call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(y), M, K, N, int(relu), stream())
+            ctx.save_for_backward(x2 if need_w else None, w, y if relu else None)
+        ctx.kept = bool(pitch)
+        ctx.mk = (M, K)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w, y = ctx.saved_tensors
-        M, K = x2.shape
+        xs, w, y = ctx.saved_tensors
+        M, K = ctx.mk
         N = w.shape[0]
         dy2 = _f32c(dy).reshape(M, N)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx = torch.empty_like(x2) if need_x else None
+        dx = torch.empty((M, K), device=dy.device, dtype=torch.float32) if need_x else None
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b else None
         scratch = torch.empty_like(dy2) if y is not None else None
-        call("mmskin_linear_backward", ptr(dy2), ptr(x2), ptr(w), ptr(y), ptr(scratch), ptr(dx), ptr(dw), ptr(db),
-             M, K, N, stream())
+        if ctx.kept:
+            call("mmskin_linear_backward_keep", ptr(dy2), ptr(xs), ptr(w), ptr(y), None, ptr(scratch), ptr(dx), ptr(dw), ptr(db),
+                 M, K, N, stream())
+        else:
+            call("mmskin_linear_backward", ptr(dy2), ptr(xs), ptr(w), ptr(y), ptr(scratch), ptr(dx), ptr(dw), ptr(db),
+                 M, K, N, stream())
         return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None
 
 
@@ -1010,7 +1024,7 @@ gelu = GeluFn.apply
 class LinearGeluFn(torch.autograd.Function):
     """h = gelu(x @ w.T + b) with gradients (first half of a transformer MLP).  Forward: Linear, then GELU (the pre-activation z is kept
     for the backward); backward: ONE C call -- gelu'(z) is applied inside the pass that converts dh for the bf16 GEMMs and sums it for
-    db (mmskin_linear_gelu_backward), so d(z) is never written in fp32."""
+    db (mmskin_linear_gelu_backward), so d(z) is never written in fp32.  The bf16 operand copy of x is kept as in LinearFn."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -1020,28 +1034,40 @@ class LinearGeluFn(torch.autograd.Function):
         M, K = x2.shape
         N = w.shape[0]
         z = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(z), M, K, N, 0, stream())
+        need_w = ctx.needs_input_grad[1]
+        pitch = _lib.load().mmskin_linear_x16_pitch(M, K, N) if need_w else 0
+        if pitch:
+            x16 = torch.empty((M, pitch), device=x.device, dtype=torch.bfloat16)
+            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), ptr(z), ptr(x16), M, K, N, 0, stream())
+            ctx.save_for_backward(x16, w, z)
+        else:
+            call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(z), M, K, N, 0, stream())
+            ctx.save_for_backward(x2 if need_w else None, w, z)
         h = torch.empty_like(z)
         call("mmskin_gelu_forward", ptr(z), ptr(h), z.numel(), stream())
-        ctx.save_for_backward(x2, w, z)
+        ctx.kept = bool(pitch)
+        ctx.mk = (M, K)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         return h.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dh):
-        x2, w, z = ctx.saved_tensors
-        M, K = x2.shape
+        xs, w, z = ctx.saved_tensors
+        M, K = ctx.mk
         N = w.shape[0]
         dh2 = _f32c(dh).reshape(M, N)
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx = torch.empty_like(x2) if need_x else None
+        dx = torch.empty((M, K), device=dh.device, dtype=torch.float32) if need_x else None
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty(N, device=dh.device, dtype=torch.float32) if need_b else None
         # off the bf16-operand large-GEMM path (head.hip: linear_big / linear_big_padded) the C side applies gelu'(z) in a pass of its own
         fused = get_linear_dtype() == "bf16" and M >= 2048 and K % 8 == 0 and N % 8 == 0 and K >= 32 and N >= 32
         scratch = None if fused else torch.empty_like(dh2)
-        call("mmskin_linear_gelu_backward", ptr(dh2), ptr(x2), ptr(w), ptr(z), ptr(scratch), ptr(dx), ptr(dw), ptr(db), M, K, N, stream())
+        if ctx.kept:
+            call("mmskin_linear_backward_keep", ptr(dh2), ptr(xs), ptr(w), None, ptr(z), ptr(scratch), ptr(dx), ptr(dw), ptr(db), M, K, N, stream())
+        else:
+            call("mmskin_linear_gelu_backward", ptr(dh2), ptr(xs), ptr(w), ptr(z), ptr(scratch), ptr(dx), ptr(dw), ptr(db), M, K, N, stream())
         return (dx.reshape(ctx.xshape) if need_x else None), dw, db
 
 
