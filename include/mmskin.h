@@ -161,6 +161,11 @@ int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, f
                                void* stream);
 int mmskin_linear_backward_keep(const float* dy, const void* x16, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
                                 float* dx, float* dw, float* db, int M, int K, int N, void* stream);
+/* A transformer MLP (timm Mlp: fc1 -> GELU -> fc2) with gradients, without gelu(z) in fp32: mmskin_gelu_forward_bf16 writes
+ * h16 [rows][cols_pad] = bf16(gelu(z)) (zero pad columns; cols_pad = mmskin_linear_x16_pitch of the second Linear), and
+ * mmskin_linear_forward_x16 runs the second Linear on it; the backward hands h16 to mmskin_linear_backward_keep. */
+int mmskin_gelu_forward_bf16(const float* z, void* h16, int64_t rows, int cols, int cols_pad, void* stream);
+int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* stream);
 /* y = LN(x)*g + b over the last dim, optional fused ReLU; mean/rstd [M] saved for backward */
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                              int M, int N, float eps, int relu, void* stream);

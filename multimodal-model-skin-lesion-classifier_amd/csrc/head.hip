@@ -1320,6 +1320,23 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 __global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   EW_LOOP(n) y[i] = 0.5f * x[i] * (1.f + erff(x[i] * 0.70710678118654752f));
 }
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// h16 [rows][cols_pad] (bf16, zero pad columns) = gelu(z [rows][cols]): the operand of the MLP's second Linear straight from the
+// pre-activation -- gelu(z) is never written in fp32 (4 values per thread)
+__global__ void gelu_to_bf16_kernel(const float* __restrict__ z, bf16_t* __restrict__ h16, int64_t rows, int cols, int cols_pad) {
+  const int cpr = cols_pad / 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows * cpr; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 4;
+    uint2 o = make_uint2(0u, 0u);
+    if (c < cols) {
+      const float4 v = *reinterpret_cast<const float4*>(z + r * cols + c);
+      o = make_uint2(f32_to_bf16_bits(gelu_exact(v.x)) | (f32_to_bf16_bits(gelu_exact(v.y)) << 16),
+                     f32_to_bf16_bits(gelu_exact(v.z)) | (f32_to_bf16_bits(gelu_exact(v.w)) << 16));
+    }
+    *reinterpret_cast<uint2*>(h16 + r * cols_pad + c) = o;
+  }
+}
 __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, int64_t n) {
   EW_LOOP(n) {
     const float v = x[i];
@@ -1334,9 +1351,12 @@ extern "C" {
 
 // x16_keep (optional): the bf16 copy of x the GEMM consumes is written THERE ([M][mmskin_linear_x16_pitch]) instead of into library
 // scratch, so the caller can hand it back to the backward's weight-gradient GEMM (no second conversion of x, half the saved bytes).
+// x16_in (optional, instead of x): the operand is already there in bf16 ([M][mmskin_linear_x16_pitch], zero pad columns).
 static int linear_forward_impl(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* x16_keep,
-                               void* stream) {
-  ARG_CHECK(x && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+                               void* stream, const void* x16_in = nullptr) {
+  ARG_CHECK((x || x16_in) && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
+  ARG_CHECK(!x16_in || (linear_bf16() && (linear_big_padded(M, K, N) || linear_big(M, K, N))),
+            "linear_forward: a bf16 operand needs the bf16 large-GEMM path (shape / mode)");
   ARG_CHECK(relu >= 0 && relu <= 2, "linear_forward: activation %d (0 none, 1 ReLU, 2 exact GELU)", relu);
   if (linear_bf16() && linear_big_padded(M, K, N)) {
     const int Kp = pad64(K), Np = pad64(N);
@@ -1344,10 +1364,14 @@ static int linear_forward_impl(const float* x, const float* w, const float* b, f
     const size_t xb = align_up((size_t)M * Kp * 2, 256), wb = align_up((size_t)Np * Kp * 2, 256), yb = align_up((size_t)M * Np * 2, 256);
     unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb + yb));
     if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
-    bf16_t* x16 = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(x16_in);
     bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb); bf16_t* y16 = reinterpret_cast<bf16_t*>(sc + xb + wb);
     int rc;
-    if ((rc = cvt_to_bf16_pad(x, x16, M, K, M, Kp, ST(stream)))) return rc;
+    if (!x16) {
+      bf16_t* xc = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+      if ((rc = cvt_to_bf16_pad(x, xc, M, K, M, Kp, ST(stream)))) return rc;
+      x16 = xc;
+    }
     if ((rc = cvt_to_bf16_pad(w, w16, N, K, Np, Kp, ST(stream)))) return rc;
     if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, y16, nullptr, nullptr, ST(stream), nullptr))) return rc;
     return unpad_bias_act(y16, b, y, M, N, Np, relu, ST(stream));
@@ -1358,10 +1382,14 @@ static int linear_forward_impl(const float* x, const float* w, const float* b, f
     const size_t xb = align_up((size_t)M * K * 2, 256), wb = align_up((size_t)N * K * 2, 256);
     unsigned char* sc = reinterpret_cast<unsigned char*>(head_scratch(xb + wb));
     if (!sc) { mmskin_set_error("linear_forward: scratch allocation failed"); return MMSKIN_ERR_HIP; }
-    bf16_t* x16 = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+    const bf16_t* x16 = reinterpret_cast<const bf16_t*>(x16_in);
     bf16_t* w16 = reinterpret_cast<bf16_t*>(sc + xb);
     int rc;
-    if ((rc = cvt_to_bf16(x, x16, (int64_t)M * K, ST(stream)))) return rc;
+    if (!x16) {
+      bf16_t* xc = x16_keep ? reinterpret_cast<bf16_t*>(x16_keep) : reinterpret_cast<bf16_t*>(sc);
+      if ((rc = cvt_to_bf16(x, xc, (int64_t)M * K, ST(stream)))) return rc;
+      x16 = xc;
+    }
     if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, ST(stream)))) return rc;
     FwdFuse f; f.bias = b; f.relu = relu == 1; f.gelu = relu == 2; f.out_f32 = y;
     return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, ST(stream), &f);
@@ -1389,6 +1417,20 @@ int mmskin_linear_x16_pitch(int M, int K, int N) {
   if (linear_big_padded(M, K, N)) return pad64(K);
   if (linear_big(M, K, N)) return K;
   return 0;
+}
+// y = act(x16 w^T + b) with the operand already in bf16 (e.g. written by mmskin_gelu_forward_bf16): no conversion pass
+int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* stream) {
+  ARG_CHECK(x16, "linear_forward_x16: null operand");
+  return linear_forward_impl(nullptr, w, b, y, M, K, N, relu, nullptr, stream, x16);
+}
+int mmskin_gelu_forward_bf16(const float* z, void* h16, int64_t rows, int cols, int cols_pad, void* stream) {
+  ARG_CHECK(z && h16 && rows > 0 && cols > 0 && cols % 4 == 0 && cols_pad % 4 == 0 && cols_pad >= cols, "gelu_forward_bf16: bad argument");
+  const int64_t n = rows * (cols_pad / 4);
+  int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(gelu_to_bf16_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, ST(stream), z,
+                     reinterpret_cast<bf16_t*>(h16), rows, cols, cols_pad);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
 }
 int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, float* y, void* x16_keep, int M, int K, int N, int relu,
                                void* stream) {

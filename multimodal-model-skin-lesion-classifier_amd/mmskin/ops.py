@@ -1071,6 +1071,64 @@ class LinearGeluFn(torch.autograd.Function):
         return (dx.reshape(ctx.xshape) if need_x else None), dw, db
 
 
+@no_second_order
+class MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) with gradients (timm Mlp.forward) on the bf16-operand large-GEMM path: the hidden activation exists only as the
+    pre-activation z (fp32, for GELU's derivative) and as the bf16 operand of fc2 -- gelu(z) is never written in fp32.  Backward: two C
+    calls (fc2's, then fc1's with gelu'(z) inside the conversion pass), each on the bf16 operand copy kept from the forward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p1, p2):
+        _need_gpu(x, "mlp")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w1, w2 = _f32c(w1), _f32c(w2)
+        M, K = x2.shape
+        Hd, N = w1.shape[0], w2.shape[0]
+        z = torch.empty((M, Hd), device=x.device, dtype=torch.float32)
+        x16 = torch.empty((M, p1), device=x.device, dtype=torch.bfloat16)
+        call("mmskin_linear_forward_keep", ptr(x2), ptr(w1), ptr(b1), ptr(z), ptr(x16), M, K, Hd, 0, stream())
+        h16 = torch.empty((M, p2), device=x.device, dtype=torch.bfloat16)
+        call("mmskin_gelu_forward_bf16", ptr(z), ptr(h16), M, Hd, p2, stream())
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        call("mmskin_linear_forward_x16", ptr(h16), ptr(w2), ptr(b2), ptr(y), M, Hd, N, 0, stream())
+        ctx.save_for_backward(x16, w1, z, h16, w2)
+        ctx.dims = (M, K, Hd, N)
+        ctx.bias = (b1 is not None, b2 is not None)
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, w1, z, h16, w2 = ctx.saved_tensors
+        M, K, Hd, N = ctx.dims
+        dy2 = _f32c(dy).reshape(M, N)
+        ng = ctx.needs_input_grad
+        dev = dy.device
+        dh = torch.empty((M, Hd), device=dev, dtype=torch.float32)
+        dw2 = torch.empty_like(w2) if ng[3] else None
+        db2 = torch.empty(N, device=dev, dtype=torch.float32) if ctx.bias[1] and ng[4] else None
+        call("mmskin_linear_backward_keep", ptr(dy2), ptr(h16), ptr(w2), None, None, None, ptr(dh), ptr(dw2), ptr(db2), M, Hd, N, stream())
+        dx = torch.empty((M, K), device=dev, dtype=torch.float32) if ng[0] else None
+        dw1 = torch.empty_like(w1) if ng[1] else None
+        db1 = torch.empty(Hd, device=dev, dtype=torch.float32) if ctx.bias[0] and ng[2] else None
+        call("mmskin_linear_backward_keep", ptr(dh), ptr(x16), ptr(w1), None, ptr(z), None, ptr(dx), ptr(dw1), ptr(db1), M, K, Hd, stream())
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dw1, db1, dw2, db2, None, None
+
+
+def mlp(x, w1, b1, w2, b2):
+    """fc2(gelu(fc1(x))).  With gradients, fp32 tensors on the GPU and both Linears on the bf16-operand large-GEMM path: MlpFn (no fp32
+    gelu(z), kept bf16 operands); otherwise linear_gelu followed by linear."""
+    if (_needs_grad(x, w1, b1, w2, b2) and x.is_cuda and x.dtype == torch.float32 and w1.dtype == torch.float32 and w2.dtype == torch.float32
+            and w1.requires_grad and w2.requires_grad):
+        M = x.numel() // x.shape[-1]
+        lib = _lib.load()
+        p1 = lib.mmskin_linear_x16_pitch(M, x.shape[-1], w1.shape[0])
+        p2 = lib.mmskin_linear_x16_pitch(M, w1.shape[0], w2.shape[0])
+        if p1 and p2:
+            return MlpFn.apply(x, w1, b1, w2, b2, p1, p2)
+    return linear(linear_gelu(x, w1, b1), w2, b2)
+
+
 def linear_gelu(x, w, b=None, out_dtype=None):
     """gelu(x @ w.T + b) -- the first half of a transformer MLP.  Without gradients (frozen encoders, inference) bias and the
     exact GELU run in the GEMM epilogue (one launch, the pre-activation never reaches memory); with gradients the two ops

@@ -56,7 +56,7 @@ class _Mlp(nn.Module):
         self.fc2 = HipLinear(dim * 4, dim)
 
     def forward(self, x):
-        return self.fc2(ops.linear_gelu(x, self.fc1.weight, self.fc1.bias))
+        return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
 
 
 class _WindowAttention(nn.Module):

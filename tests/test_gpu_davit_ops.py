@@ -163,3 +163,34 @@ def test_linear_gelu_backward_in_one_call(mode, M, K, N):
             assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
         else:   # bf16 operands: relative L2 of the whole tensor
             assert ((got - want).norm() / want.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,C", [(4096, 96), (2304, 192), (300, 64)])
+def test_mlp_fc1_gelu_fc2(mode, M, C):
+    """timm Mlp.forward (fc1 -> GELU -> fc2) as ops.mlp: in bf16-operand mode on the large-GEMM shapes MlpFn keeps the hidden
+    activation as pre-activation + bf16 operand only; elsewhere it is linear_gelu + linear.  Output and all five gradients against
+    fp64 torch; tolerance 1e-4 of the maximum in fp32, 2e-2 relative L2 with bf16 operands."""
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    w1 = torch.randn(4 * C, C, generator=g) / C ** 0.5; b1 = torch.randn(4 * C, generator=g) * 0.1
+    w2 = torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5; b2 = torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(M, C, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y_ref = F.linear(F.gelu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])
+    y_ref.backward(dy.double())
+    prev = ops.get_linear_dtype()
+    ops.set_linear_dtype(mode)
+    try:
+        dev = [t.to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = ops.mlp(*dev)
+        y.backward(dy.to(DEV))
+    finally:
+        ops.set_linear_dtype(prev)
+    pairs = [(y, y_ref)] + [(d.grad, r.grad) for d, r in zip(dev, ref)]
+    for got, want in pairs:
+        got, want = got.detach().cpu().double(), want.detach()
+        if mode == "fp32" or M < 2048:
+            assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
+        else:
+            assert ((got - want).norm() / want.norm()).item() < 2e-2
