@@ -157,15 +157,16 @@ int mmskin_linear_gelu_backward(const float* dh, const float* x, const float* w,
  * output of a fused ReLU or pre-activation of a following GELU, at most one, as in mmskin_linear_backward / _gelu_backward).
  * Same arithmetic as mmskin_linear_forward / _backward: the kept copy is the tensor the scratch conversion would have produced. */
 int mmskin_linear_x16_pitch(int M, int K, int N);
-int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, float* y, void* x16_keep, int M, int K, int N, int relu,
-                               void* stream);
+int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, const float* res, float* y, void* x16_keep, int M, int K,
+                               int N, int relu, void* stream);   /* res (optional, fp32 [M][N]): y = res + act(x w^T + b) */
 int mmskin_linear_backward_keep(const float* dy, const void* x16, const float* w, const float* y_relu, const float* z_gelu, float* dy_scratch,
                                 float* dx, float* dw, float* db, int M, int K, int N, void* stream);
 /* A transformer MLP (timm Mlp: fc1 -> GELU -> fc2) with gradients, without gelu(z) in fp32: mmskin_gelu_forward_bf16 writes
  * h16 [rows][cols_pad] = bf16(gelu(z)) (zero pad columns; cols_pad = mmskin_linear_x16_pitch of the second Linear), and
  * mmskin_linear_forward_x16 runs the second Linear on it; the backward hands h16 to mmskin_linear_backward_keep. */
 int mmskin_gelu_forward_bf16(const float* z, void* h16, int64_t rows, int cols, int cols_pad, void* stream);
-int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* stream);
+int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, const float* res, float* y, int M, int K, int N, int relu,
+                              void* stream);                     /* res as above: the block's skip connection in the same pass */
 /* y = LN(x)*g + b over the last dim, optional fused ReLU; mean/rstd [M] saved for backward */
 int mmskin_layernorm_forward(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd,
                              int M, int N, float eps, int relu, void* stream);

@@ -261,7 +261,7 @@ __global__ void f32_to_bf16_pad_kernel(const float* __restrict__ in, bf16_t* __r
 }
 // out [rows][cols] fp32 <- act(in [rows][cols_pad] bf16 + bias); act 0 none / 1 ReLU / 2 exact GELU
 __global__ void bf16_unpad_bias_act_kernel(const bf16_t* __restrict__ in, const float* __restrict__ bias, float* __restrict__ out,
-                                           int64_t rows, int cols, int cols_pad, int act) {
+                                           int64_t rows, int cols, int cols_pad, int act, const float* __restrict__ res) {
   const int cpr = cols / 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows * cpr; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / cpr;
@@ -274,6 +274,10 @@ __global__ void bf16_unpad_bias_act_kernel(const bf16_t* __restrict__ in, const 
       if (act == 1) t = fmaxf(t, 0.f);
       else if (act == 2) t = 0.5f * t * (1.f + erff(t * 0.70710678118654752f));
       v.v[e] = t;
+    }
+    if (res) {   // y = residual + act(...): the block's skip connection in the same pass
+      const float4 r0 = *reinterpret_cast<const float4*>(res + r * cols + c), r1 = *reinterpret_cast<const float4*>(res + r * cols + c + 4);
+      v.v[0] += r0.x; v.v[1] += r0.y; v.v[2] += r0.z; v.v[3] += r0.w; v.v[4] += r1.x; v.v[5] += r1.y; v.v[6] += r1.z; v.v[7] += r1.w;
     }
     *reinterpret_cast<float4*>(out + r * cols + c) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
     *reinterpret_cast<float4*>(out + r * cols + c + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
@@ -300,10 +304,11 @@ static int cvt_to_bf16_pad(const float* in, bf16_t* out, int64_t rows, int cols,
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
-static int unpad_bias_act(const bf16_t* in, const float* bias, float* out, int64_t rows, int cols, int cols_pad, int act, hipStream_t st) {
+static int unpad_bias_act(const bf16_t* in, const float* bias, float* out, int64_t rows, int cols, int cols_pad, int act, hipStream_t st,
+                          const float* res = nullptr) {
   const int64_t n = rows * (cols / 8);
   int64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(bf16_unpad_bias_act_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, bias, out, rows, cols, cols_pad, act);
+  hipLaunchKernelGGL(bf16_unpad_bias_act_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, st, in, bias, out, rows, cols, cols_pad, act, res);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -1317,6 +1322,14 @@ __global__ void gelu_tanh_bwd_kernel(const float* __restrict__ dy, const float* 
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n, int64_t nb) {
   EW_LOOP(n) y[i] = a[i] + b[i % nb];   // b broadcasts over the leading dimension when nb < n
 }
+__global__ void add4_inplace_kernel(float* __restrict__ y, const float* __restrict__ b, int64_t n4) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(y)[i];
+    const float4 c = reinterpret_cast<const float4*>(b)[i];
+    a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w;
+    reinterpret_cast<float4*>(y)[i] = a;
+  }
+}
 __global__ void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   EW_LOOP(n) y[i] = 0.5f * x[i] * (1.f + erff(x[i] * 0.70710678118654752f));
 }
@@ -1352,8 +1365,11 @@ extern "C" {
 // x16_keep (optional): the bf16 copy of x the GEMM consumes is written THERE ([M][mmskin_linear_x16_pitch]) instead of into library
 // scratch, so the caller can hand it back to the backward's weight-gradient GEMM (no second conversion of x, half the saved bytes).
 // x16_in (optional, instead of x): the operand is already there in bf16 ([M][mmskin_linear_x16_pitch], zero pad columns).
+// res (optional, bf16 large-GEMM path only): y = res + act(x w^T + b), res fp32 [M][N] -- the residual add of a transformer block.
 static int linear_forward_impl(const float* x, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* x16_keep,
-                               void* stream, const void* x16_in = nullptr) {
+                               void* stream, const void* x16_in = nullptr, const float* res = nullptr) {
+  ARG_CHECK(!res || (linear_bf16() && (linear_big_padded(M, K, N) || linear_big(M, K, N))),
+            "linear_forward: the fused residual needs the bf16 large-GEMM path (shape / mode)");
   ARG_CHECK((x || x16_in) && w && y && M > 0 && K > 0 && N > 0, "linear_forward: bad argument");
   ARG_CHECK(!x16_in || (linear_bf16() && (linear_big_padded(M, K, N) || linear_big(M, K, N))),
             "linear_forward: a bf16 operand needs the bf16 large-GEMM path (shape / mode)");
@@ -1374,7 +1390,7 @@ static int linear_forward_impl(const float* x, const float* w, const float* b, f
     }
     if ((rc = cvt_to_bf16_pad(w, w16, N, K, Np, Kp, ST(stream)))) return rc;
     if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, y16, nullptr, nullptr, ST(stream), nullptr))) return rc;
-    return unpad_bias_act(y16, b, y, M, N, Np, relu, ST(stream));
+    return unpad_bias_act(y16, b, y, M, N, Np, relu, ST(stream), res);
   }
   if (linear_big(M, K, N) && linear_bf16()) {
     // bf16 operands, fp32 accumulate; bias + activation + the widening to fp32 all happen in the GEMM epilogue
@@ -1391,8 +1407,16 @@ static int linear_forward_impl(const float* x, const float* w, const float* b, f
       x16 = xc;
     }
     if ((rc = cvt_to_bf16(w, w16, (int64_t)N * K, ST(stream)))) return rc;
-    FwdFuse f; f.bias = b; f.relu = relu == 1; f.gelu = relu == 2; f.out_f32 = y;
-    return launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, ST(stream), &f);
+    const bool res_epi = res && N % 128 == 0;   // the residual epilogue stores whole 128-column tiles; other widths add in a pass of their own
+    FwdFuse f; f.bias = b; f.relu = relu == 1; f.gelu = relu == 2; f.out_f32 = y; f.res_f32 = res_epi ? res : nullptr;
+    if ((rc = launch_conv_fwd<bf16_t>(s, x16, w16, reinterpret_cast<bf16_t*>(y), nullptr, nullptr, ST(stream), &f))) return rc;
+    if (res && !res_epi) {
+      const int64_t n4 = (int64_t)M * N / 4;
+      int64_t blocks = (n4 + 255) / 256;
+      hipLaunchKernelGGL(add4_inplace_kernel, dim3((unsigned)(blocks > 1048576 ? 1048576 : blocks)), dim3(256), 0, ST(stream), y, res, n4);
+      HIP_CHECK_RET(hipGetLastError());
+    }
+    return MMSKIN_OK;
   }
   if (linear_big(M, K, N)) {   // tokens x hidden GEMMs of the text encoders: the exact-f32 implicit-GEMM kernel as a 1x1 conv
     ConvShape s = {M, 1, 1, K, N, 1, 1, 1, 0};
@@ -1419,9 +1443,10 @@ int mmskin_linear_x16_pitch(int M, int K, int N) {
   return 0;
 }
 // y = act(x16 w^T + b) with the operand already in bf16 (e.g. written by mmskin_gelu_forward_bf16): no conversion pass
-int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, float* y, int M, int K, int N, int relu, void* stream) {
+int mmskin_linear_forward_x16(const void* x16, const float* w, const float* b, const float* res, float* y, int M, int K, int N, int relu,
+                              void* stream) {
   ARG_CHECK(x16, "linear_forward_x16: null operand");
-  return linear_forward_impl(nullptr, w, b, y, M, K, N, relu, nullptr, stream, x16);
+  return linear_forward_impl(nullptr, w, b, y, M, K, N, relu, nullptr, stream, x16, res);
 }
 int mmskin_gelu_forward_bf16(const float* z, void* h16, int64_t rows, int cols, int cols_pad, void* stream) {
   ARG_CHECK(z && h16 && rows > 0 && cols > 0 && cols % 4 == 0 && cols_pad % 4 == 0 && cols_pad >= cols, "gelu_forward_bf16: bad argument");
@@ -1432,10 +1457,10 @@ int mmskin_gelu_forward_bf16(const float* z, void* h16, int64_t rows, int cols, 
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
-int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, float* y, void* x16_keep, int M, int K, int N, int relu,
-                               void* stream) {
+int mmskin_linear_forward_keep(const float* x, const float* w, const float* b, const float* res, float* y, void* x16_keep, int M, int K,
+                               int N, int relu, void* stream) {
   ARG_CHECK(x16_keep && mmskin_linear_x16_pitch(M, K, N) > 0, "linear_forward_keep: no bf16 operand copy for this shape / mode");
-  return linear_forward_impl(x, w, b, y, M, K, N, relu, x16_keep, stream);
+  return linear_forward_impl(x, w, b, y, M, K, N, relu, x16_keep, stream, nullptr, res);
 }
 
 // Linear with bf16 tensors at either end (the inference lane of the transformer encoders in bf16-operand mode): x and / or y may be

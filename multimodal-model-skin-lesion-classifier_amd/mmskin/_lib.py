@@ -69,10 +69,10 @@ _SIGNATURES = {
     "mmskin_linear_backward": (_i, [_P] * 8 + [_i] * 3 + [_P]),
     "mmskin_linear_gelu_backward": (_i, [_P] * 8 + [_i] * 3 + [_P]),
     "mmskin_linear_x16_pitch": (_i, [_i, _i, _i]),
-    "mmskin_linear_forward_keep": (_i, [_P] * 5 + [_i] * 4 + [_P]),
+    "mmskin_linear_forward_keep": (_i, [_P] * 6 + [_i] * 4 + [_P]),
     "mmskin_linear_backward_keep": (_i, [_P] * 9 + [_i] * 3 + [_P]),
     "mmskin_gelu_forward_bf16": (_i, [_P, _P, _i64, _i, _i, _P]),
-    "mmskin_linear_forward_x16": (_i, [_P] * 4 + [_i] * 4 + [_P]),
+    "mmskin_linear_forward_x16": (_i, [_P] * 5 + [_i] * 4 + [_P]),
     "mmskin_layernorm_forward": (_i, [_P] * 6 + [_i, _i, _f, _i, _P]),
     "mmskin_layernorm_backward": (_i, [_P] * 9 + [_i, _i, _i, _P]),
     "mmskin_sigmoid_gate_forward": (_i, [_P] * 3 + [_i64, _P]),

@@ -28,11 +28,12 @@ def _f32c(t):
 
 @no_second_order
 class LinearFn(torch.autograd.Function):
-    """y = x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU]).  When the bf16-operand large-GEMM path runs and w trains, the bf16
-    copy of x the forward GEMM consumed is what is saved for the weight gradient (half the bytes, no second conversion)."""
+    """y = [res +] x @ w.T + b, optional fused ReLU (nn.Linear [+ nn.ReLU] [+ the block's residual add]).  When the bf16-operand
+    large-GEMM path runs and w trains, the bf16 copy of x the forward GEMM consumed is what is saved for the weight gradient (half the
+    bytes, no second conversion); the residual is added in the pass that writes y (only offered on that path: see linear())."""
 
     @staticmethod
-    def forward(ctx, x, w, b, relu):
+    def forward(ctx, x, w, b, relu, res=None):
         _need_gpu(x, "linear")
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         w = _f32c(w)
@@ -40,18 +41,22 @@ class LinearFn(torch.autograd.Function):
         N = w.shape[0]
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
         need_w = ctx.needs_input_grad[1]
-        pitch = _lib.load().mmskin_linear_x16_pitch(M, K, N) if need_w else 0
+        pitch = _lib.load().mmskin_linear_x16_pitch(M, K, N) if (need_w or res is not None) else 0
+        if res is not None and (not pitch or relu):
+            raise RuntimeError("linear: the fused residual needs the bf16-operand large-GEMM path and no ReLU")
         if pitch:
             x16 = torch.empty((M, pitch), device=x.device, dtype=torch.bfloat16)
-            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), ptr(y), ptr(x16), M, K, N, int(relu), stream())
-            ctx.save_for_backward(x16, w, y if relu else None)
+            r2 = _f32c(res).reshape(M, N) if res is not None else None
+            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), ptr(r2), ptr(y), ptr(x16), M, K, N, int(relu), stream())
+            ctx.save_for_backward(x16 if need_w else None, w, y if relu else None)
         else:
             call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(y), M, K, N, int(relu), stream())
             ctx.save_for_backward(x2 if need_w else None, w, y if relu else None)
-        ctx.kept = bool(pitch)
+        ctx.kept = bool(pitch) and need_w
         ctx.mk = (M, K)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
+        ctx.res_shape = None if res is None else res.shape
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -71,7 +76,8 @@ class LinearFn(torch.autograd.Function):
         else:
             call("mmskin_linear_backward", ptr(dy2), ptr(xs), ptr(w), ptr(y), ptr(scratch), ptr(dx), ptr(dw), ptr(db),
                  M, K, N, stream())
-        return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None
+        dres = dy2.reshape(ctx.res_shape) if ctx.res_shape is not None and ctx.needs_input_grad[4] else None   # relu is never combined with res
+        return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None, dres
 
 
 def lane_dtype(x, module=None, *tensors):
@@ -173,9 +179,19 @@ def linear_lane(x, ws, b=None, act=0, gamma=None, residual=None, drop_p=0.0, tra
     return y.reshape(*x.shape[:-1], N)
 
 
-def linear(x, w, b=None, relu=False, out_dtype=None):
+def linear(x, w, b=None, relu=False, out_dtype=None, residual=None):
+    """nn.Linear (+ ReLU).  residual: y = residual + x @ w.T + b -- added in the pass that writes y when the bf16-operand large-GEMM
+    path takes the shape (a transformer block's skip connection), by ops.add otherwise."""
     if x.dtype == torch.bfloat16 or out_dtype == torch.bfloat16:
-        return linear_lane(x, w, b, 1 if relu else 0, out_dtype=out_dtype)
+        y = linear_lane(x, w, b, 1 if relu else 0, out_dtype=out_dtype)
+        return y if residual is None else add(y, residual.reshape(y.shape))
+    if residual is not None:
+        M = x.numel() // x.shape[-1]
+        if (not relu and x.is_cuda and x.dtype == torch.float32 and residual.dtype == torch.float32
+                and _lib.load().mmskin_linear_x16_pitch(M, x.shape[-1], w.shape[0])):
+            return LinearFn.apply(x, w, b, False, residual)
+        y = LinearFn.apply(x, w, b, relu)
+        return add(y, residual.reshape(y.shape))
     return LinearFn.apply(x, w, b, relu)
 
 
@@ -1038,7 +1054,7 @@ class LinearGeluFn(torch.autograd.Function):
         pitch = _lib.load().mmskin_linear_x16_pitch(M, K, N) if need_w else 0
         if pitch:
             x16 = torch.empty((M, pitch), device=x.device, dtype=torch.bfloat16)
-            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), ptr(z), ptr(x16), M, K, N, 0, stream())
+            call("mmskin_linear_forward_keep", ptr(x2), ptr(w), ptr(b), None, ptr(z), ptr(x16), M, K, N, 0, stream())
             ctx.save_for_backward(x16, w, z)
         else:
             call("mmskin_linear_forward", ptr(x2), ptr(w), ptr(b), ptr(z), M, K, N, 0, stream())
@@ -1073,12 +1089,13 @@ class LinearGeluFn(torch.autograd.Function):
 
 @no_second_order
 class MlpFn(torch.autograd.Function):
-    """fc2(gelu(fc1(x))) with gradients (timm Mlp.forward) on the bf16-operand large-GEMM path: the hidden activation exists only as the
-    pre-activation z (fp32, for GELU's derivative) and as the bf16 operand of fc2 -- gelu(z) is never written in fp32.  Backward: two C
-    calls (fc2's, then fc1's with gelu'(z) inside the conversion pass), each on the bf16 operand copy kept from the forward."""
+    """[res +] fc2(gelu(fc1(x))) with gradients (timm Mlp.forward and the block's skip connection) on the bf16-operand large-GEMM path:
+    the hidden activation exists only as the pre-activation z (fp32, for GELU's derivative) and as the bf16 operand of fc2 -- gelu(z)
+    is never written in fp32; the residual is added in the pass that writes the output.  Backward: two C calls (fc2's, then fc1's with
+    gelu'(z) inside the conversion pass), each on the bf16 operand copy kept from the forward."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, p1, p2):
+    def forward(ctx, x, w1, b1, w2, b2, res, p1, p2):
         _need_gpu(x, "mlp")
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         w1, w2 = _f32c(w1), _f32c(w2)
@@ -1086,15 +1103,17 @@ class MlpFn(torch.autograd.Function):
         Hd, N = w1.shape[0], w2.shape[0]
         z = torch.empty((M, Hd), device=x.device, dtype=torch.float32)
         x16 = torch.empty((M, p1), device=x.device, dtype=torch.bfloat16)
-        call("mmskin_linear_forward_keep", ptr(x2), ptr(w1), ptr(b1), ptr(z), ptr(x16), M, K, Hd, 0, stream())
+        call("mmskin_linear_forward_keep", ptr(x2), ptr(w1), ptr(b1), None, ptr(z), ptr(x16), M, K, Hd, 0, stream())
         h16 = torch.empty((M, p2), device=x.device, dtype=torch.bfloat16)
         call("mmskin_gelu_forward_bf16", ptr(z), ptr(h16), M, Hd, p2, stream())
         y = torch.empty((M, N), device=x.device, dtype=torch.float32)
-        call("mmskin_linear_forward_x16", ptr(h16), ptr(w2), ptr(b2), ptr(y), M, Hd, N, 0, stream())
+        r2 = _f32c(res).reshape(M, N) if res is not None else None
+        call("mmskin_linear_forward_x16", ptr(h16), ptr(w2), ptr(b2), ptr(r2), ptr(y), M, Hd, N, 0, stream())
         ctx.save_for_backward(x16, w1, z, h16, w2)
         ctx.dims = (M, K, Hd, N)
         ctx.bias = (b1 is not None, b2 is not None)
         ctx.xshape = x.shape
+        ctx.res_shape = None if res is None else res.shape
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -1112,21 +1131,22 @@ class MlpFn(torch.autograd.Function):
         dw1 = torch.empty_like(w1) if ng[1] else None
         db1 = torch.empty(Hd, device=dev, dtype=torch.float32) if ctx.bias[0] and ng[2] else None
         call("mmskin_linear_backward_keep", ptr(dh), ptr(x16), ptr(w1), None, ptr(z), None, ptr(dx), ptr(dw1), ptr(db1), M, K, Hd, stream())
-        return (dx.reshape(ctx.xshape) if dx is not None else None), dw1, db1, dw2, db2, None, None
+        dres = dy2.reshape(ctx.res_shape) if ctx.res_shape is not None and ng[5] else None
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dw1, db1, dw2, db2, dres, None, None
 
 
-def mlp(x, w1, b1, w2, b2):
-    """fc2(gelu(fc1(x))).  With gradients, fp32 tensors on the GPU and both Linears on the bf16-operand large-GEMM path: MlpFn (no fp32
-    gelu(z), kept bf16 operands); otherwise linear_gelu followed by linear."""
+def mlp(x, w1, b1, w2, b2, residual=None):
+    """[residual +] fc2(gelu(fc1(x))).  With gradients, fp32 tensors on the GPU and both Linears on the bf16-operand large-GEMM path:
+    MlpFn (no fp32 gelu(z), kept bf16 operands, residual added by the output pass); otherwise linear_gelu, linear and add."""
     if (_needs_grad(x, w1, b1, w2, b2) and x.is_cuda and x.dtype == torch.float32 and w1.dtype == torch.float32 and w2.dtype == torch.float32
-            and w1.requires_grad and w2.requires_grad):
+            and w1.requires_grad and w2.requires_grad and (residual is None or residual.dtype == torch.float32)):
         M = x.numel() // x.shape[-1]
         lib = _lib.load()
         p1 = lib.mmskin_linear_x16_pitch(M, x.shape[-1], w1.shape[0])
         p2 = lib.mmskin_linear_x16_pitch(M, w1.shape[0], w2.shape[0])
         if p1 and p2:
-            return MlpFn.apply(x, w1, b1, w2, b2, p1, p2)
-    return linear(linear_gelu(x, w1, b1), w2, b2)
+            return MlpFn.apply(x, w1, b1, w2, b2, residual, p1, p2)
+    return linear(linear_gelu(x, w1, b1), w2, b2, residual=residual)
 
 
 def linear_gelu(x, w, b=None, out_dtype=None):

@@ -55,8 +55,8 @@ class _Mlp(nn.Module):
         self.act = nn.GELU()
         self.fc2 = HipLinear(dim * 4, dim)
 
-    def forward(self, x):
-        return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+    def forward(self, x, residual=None):      # [residual +] fc2(gelu(fc1(x)))
+        return ops.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual=residual)
 
 
 class _WindowAttention(nn.Module):
@@ -81,17 +81,17 @@ class _ChannelAttention(nn.Module):
         self.qkv = HipLinear(dim, dim * 3)
         self.proj = HipLinear(dim, dim)
 
-    def forward(self, x, B, N):       # x [B*N, C]
+    def forward(self, x, B, N, residual=None):       # x [B*N, C] -> [residual +] proj(attention)
         C = x.shape[1]
         G, Dh = self.groups, x.shape[1] // self.groups
         qkv = self.qkv(x).reshape(B, N, 3, G, Dh)
         if ops.channel_attention_ok(qkv):     # token-major in and out: no transposing copies around the attention
-            return self.proj(ops.channel_attention(qkv, N ** -0.5).reshape(B * N, C))
+            return ops.linear(ops.channel_attention(qkv, N ** -0.5).reshape(B * N, C), self.proj.weight, self.proj.bias, residual=residual)
         qkv = qkv.permute(2, 0, 3, 4, 1).contiguous()      # [3, B, G, Dh, N]: channels attend over tokens
         # softmax((q * N^-0.5)^T k) over the key channels, applied to v^T: an attention with "sequence" = the Dh channels of a
         # group and "feature" = the N tokens; ops.attention scales by feature^-0.5 = N^-0.5, exactly timm's dynamic_scale
         o = ops.attention(qkv[0], qkv[1], qkv[2])                                          # [B, G, Dh, N]
-        return self.proj(o.permute(0, 3, 1, 2).reshape(B * N, C))
+        return ops.linear(o.permute(0, 3, 1, 2).reshape(B * N, C), self.proj.weight, self.proj.bias, residual=residual)
 
 
 class _SpatialBlock(nn.Module):
@@ -119,15 +119,21 @@ class _SpatialBlock(nn.Module):
         # tokens where they sit (ops.window_attention) -- window_partition / window_reverse of timm's SpatialBlock without copies
         qkv = self.attn.qkv(h.reshape(B * Hp * Wp, C)).reshape(B, Hp, Wp, 3, heads, C // heads)
         if ops.window_attention_ok(qkv, ws):
-            a = self.attn.proj(ops.window_attention(qkv, ws).reshape(B * Hp * Wp, C)).reshape(B, Hp, Wp, C)
+            o = ops.window_attention(qkv, ws).reshape(B * Hp * Wp, C)
+            if not (ph or pw):    # the skip connection rides on the projection's output pass
+                return self._tail(ops.linear(o, self.attn.proj.weight, self.attn.proj.bias, residual=shortcut.reshape(B * H * W, C)).reshape(B, H, W, C))
+            a = self.attn.proj(o).reshape(B, Hp, Wp, C)
         else:
             win = h.reshape(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C).contiguous()
             a = self.attn(win).reshape(B, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
         if ph or pw:
             a = a[:, :H, :W, :].contiguous()
-        x = self.cpe2(ops.add(shortcut, a))
-        m = self.mlp(_layernorm(self.norm2, x.reshape(B * H * W, C)))
-        return ops.add(x, m.reshape(B, H, W, C))
+        return self._tail(ops.add(shortcut, a))
+
+    def _tail(self, x):               # x = shortcut + attention
+        B, H, W, C = x.shape
+        x = self.cpe2(x)
+        return self.mlp(_layernorm(self.norm2, x.reshape(B * H * W, C)), residual=x.reshape(B * H * W, C)).reshape(B, H, W, C)
 
 
 class _ChannelBlock(nn.Module):
@@ -143,10 +149,8 @@ class _ChannelBlock(nn.Module):
     def forward(self, x):
         B, H, W, C = x.shape
         x = self.cpe1(x)
-        a = self.attn(_layernorm(self.norm1, x.reshape(B * H * W, C)), B, H * W)
-        x = self.cpe2(ops.add(x, a.reshape(B, H, W, C)))
-        m = self.mlp(_layernorm(self.norm2, x.reshape(B * H * W, C)))
-        return ops.add(x, m.reshape(B, H, W, C))
+        x = self.cpe2(self.attn(_layernorm(self.norm1, x.reshape(B * H * W, C)), B, H * W, residual=x.reshape(B * H * W, C)).reshape(B, H, W, C))
+        return self.mlp(_layernorm(self.norm2, x.reshape(B * H * W, C)), residual=x.reshape(B * H * W, C)).reshape(B, H, W, C)
 
 
 class _Stem(nn.Module):

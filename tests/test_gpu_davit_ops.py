@@ -194,3 +194,38 @@ def test_mlp_fc1_gelu_fc2(mode, M, C):
             assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
         else:
             assert ((got - want).norm() / want.norm()).item() < 2e-2
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,K", [(4096, 96), (2304, 192), (2048, 384), (100, 64)])
+def test_linear_and_mlp_with_fused_residual(mode, M, K):
+    """residual + x w^T + b and residual + fc2(gelu(fc1(x))) (a transformer block's skip connections riding on the output pass of the
+    bf16 large-GEMM path -- padded 96-wide, 192-wide (separate add: the residual epilogue stores 128-column tiles) and 384-wide --
+    and ops.add elsewhere): outputs and the gradients w.r.t. the residual and x against fp64 torch."""
+    g = torch.Generator().manual_seed(M + K + 1)
+    x = torch.randn(M, K, generator=g); res = torch.randn(M, K, generator=g)
+    w = torch.randn(K, K, generator=g) / K ** 0.5; b = torch.randn(K, generator=g) * 0.1
+    w1 = torch.randn(4 * K, K, generator=g) / K ** 0.5; b1 = torch.randn(4 * K, generator=g) * 0.1
+    w2 = torch.randn(K, 4 * K, generator=g) / (4 * K) ** 0.5; b2 = torch.randn(K, generator=g) * 0.1
+    dy = torch.randn(M, K, generator=g)
+    prev = ops.get_linear_dtype()
+    ops.set_linear_dtype(mode)
+    try:
+        for case in ("linear", "mlp"):
+            rx, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+            dx_, dr_ = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+            if case == "linear":
+                y_ref = rr + F.linear(rx, w.double(), b.double())
+                y = ops.linear(dx_, w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True), residual=dr_)
+            else:
+                y_ref = rr + F.linear(F.gelu(F.linear(rx, w1.double(), b1.double())), w2.double(), b2.double())
+                y = ops.mlp(dx_, *(t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)), residual=dr_)
+            y_ref.backward(dy.double()); y.backward(dy.to(DEV))
+            for got, want in ((y, y_ref), (dx_.grad, rx.grad), (dr_.grad, rr.grad)):
+                got, want = got.detach().cpu().double(), want.detach()
+                if mode == "fp32" or M < 2048:
+                    assert (got - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item()), case
+                else:
+                    assert ((got - want).norm() / want.norm()).item() < 2e-2, case
+    finally:
+        ops.set_linear_dtype(prev)
