@@ -40,7 +40,7 @@ struct Plan : PlanBase {
   int64_t staged_elems = 0;
   // workspace layout (bytes)
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[7], off_slab, off_partial,
-      off_coefbwd, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
+      off_coefbwd, off_coefbwd_b, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
   size_t maxact_bytes = 0, stat_bytes = 0;
 
   int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
@@ -200,6 +200,7 @@ int build_plan(Plan& p) {
   p.off_partial = carve(cur, partial_max);
   p.off_partial_b = carve(cur, partial_max);
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
+  p.off_coefbwd_b = carve(cur, 3 * (size_t)maxC * sizeof(float));   // the downsample branch's own coefficients (its stream in backward)
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.off_red_b = carve(cur, bn_reduce_scratch_bytes(maxC));
@@ -408,18 +409,22 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   float* partial_b = reinterpret_cast<float*>(ws + p.off_partial_b);
   // BN backward of unit u when `dz` is ALREADY masked and its partial sums (sum dz, sum dz*x) were
   // produced by the epilogue of the dgrad launch that wrote dz: finalize + one apply pass.
-  auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx) -> int {
+  // on_branch: the downsample branch on its own stream (own coefficient and reduction scratch)
+  auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx, bool on_branch = false) -> int {
     const int C = u.s.Cout;
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
     const T* x = reinterpret_cast<const T*>(ws + u.x_off);
-    float* cB = cA + C; float* cC = cA + 2 * C;
+    float* kA = on_branch ? reinterpret_cast<float*>(ws + p.off_coefbwd_b) : cA;
+    float* cB = kA + C; float* cC = kA + 2 * C;
+    hipStream_t bs = on_branch ? p.side.s2 : st;
+    double* red = reinterpret_cast<double*>(ws + (on_branch ? p.off_red_b : p.off_red));
     int r;
     p.prof.begin(K_BN_BWD, st);
     struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
     if (p.prof.on) p.prof.bytes[K_BN_BWD] += 3.0 * u.rows() * C * sizeof(T);
     if ((r = bn_bwd_finalize(part, nrows, C, (double)u.rows(), params + u.g_off, coef + 2 * C, coef + 3 * C,
-                             grads + u.g_off, grads + u.b_off, cA, cB, cC, reinterpret_cast<double*>(ws + p.off_red), st))) return r;
-    return bn_bwd_apply<T>(dz, x, nullptr, coef, coef + C, MASK_NONE, cA, cB, cC, dx, nullptr, u.rows(), C, st);
+                             grads + u.g_off, grads + u.b_off, kA, cB, cC, red, bs))) return r;
+    return bn_bwd_apply<T>(dz, x, nullptr, coef, coef + C, MASK_NONE, kA, cB, cC, dx, nullptr, u.rows(), C, bs);
   };
 
   Unit& last = p.units[p.blocks.back().units.back()];
@@ -432,16 +437,18 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   const bool use_side = !side_off && !p.prof.on;
   if (use_side && (rc = p.side.init())) return rc;
   for (int i = 0; i < 3; ++i) p.side.done_valid[i] = false;
+  static const bool ds_stream = [] { const char* v = getenv("MMSKIN_BWD_DS_STREAM"); return !v || atoi(v) != 0; }();
   T* DX[3] = {S[2], S[6], S[5]};
   // main stream may overwrite buffer i only after the wgrad that reads it has finished
   auto acquire = [&](int i) -> int {
     if (use_side && p.side.done_valid[i]) HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.done[i], 0));
     return MMSKIN_OK;
   };
-  auto wgrad_async = [&](Unit& u, int i, const T* uin) -> int {
+  // from: the stream that produced DX[i] (the main stream, or the downsample branch's)
+  auto wgrad_async = [&](Unit& u, int i, const T* uin, hipStream_t from = nullptr) -> int {
     hipStream_t ws_st = st;
     if (use_side) {
-      HIP_CHECK_RET(hipEventRecord(p.side.ready[i], st));
+      HIP_CHECK_RET(hipEventRecord(p.side.ready[i], from ? from : st));
       HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.ready[i], 0));
       ws_st = p.side.s;
     }
@@ -470,14 +477,24 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     T* dZ = S[4];
     T* dXd = DX[2];
     const bool has_ds = b.ds >= 0;
+    // The downsample branch (BatchNorm-backward apply, dgrad) only has to be done when conv1's dgrad takes its result as the
+    // addend: it runs on its own stream beside conv3 .. conv2 (as in the forward) -- ~0.9 ms of launches per ResNet-50 step that
+    // sat on the main chain.  The main stream hands it g + partial_b (d_ready) and takes gin back (d_done).
+    const bool ds_branch = has_ds && use_side && ds_stream && fused_ready;
     const T* dz_final;   // masked gradient of the block output (residual branch addend)
     dxi ^= 1;
     if ((rc = acquire(dxi))) return rc;
-    if (has_ds && (rc = acquire(2))) return rc;
+    if (has_ds && !ds_branch && (rc = acquire(2))) return rc;
     T* dX = DX[dxi];
     if (fused_ready) {
+      if (ds_branch) {
+        HIP_CHECK_RET(hipEventRecord(p.side.d_ready, st));
+        HIP_CHECK_RET(hipStreamWaitEvent(p.side.s2, p.side.d_ready, 0));
+        if (p.side.done_valid[2]) HIP_CHECK_RET(hipStreamWaitEvent(p.side.s2, p.side.done[2], 0));   // the last wgrad that read dXd
+        if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd, true))) return rc;
+      }
       if ((rc = bn_backward_fused(ul, g, partial, fused_rows, dX))) return rc;
-      if (has_ds)
+      if (has_ds && !ds_branch)
         if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd))) return rc;
       dz_final = g;
     } else {
@@ -506,8 +523,15 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         const T* addend = dz_final;
         if (has_ds) {
           Unit& d = p.units[b.ds];
-          if ((rc = wgrad_async(d, 2, in))) return rc;
-          PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
+          if (ds_branch) {
+            if ((rc = wgrad_async(d, 2, in, p.side.s2))) return rc;
+            if ((rc = launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, p.side.s2))) return rc;
+            HIP_CHECK_RET(hipEventRecord(p.side.d_done, p.side.s2));
+            HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.d_done, 0));
+          } else {
+            if ((rc = wgrad_async(d, 2, in))) return rc;
+            PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
+          }
           addend = gin;   // main-branch dgrad accumulates on top, in place
         }
         DgradFuse f;

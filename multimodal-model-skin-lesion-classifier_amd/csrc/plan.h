@@ -48,6 +48,9 @@ struct SideStream {
   bool done_valid[3] = {false, false, false};
   hipEvent_t f_ready = nullptr, f_done = nullptr;      // forward: block input ready / downsample branch finished
   hipEvent_t f_staged = nullptr;                       // forward: weights of the residual stages staged (beside the stem)
+  // backward: the downsample branch of a block (BatchNorm-backward apply + dgrad) on a stream of its own, beside conv3 .. conv2
+  hipStream_t s2 = nullptr;
+  hipEvent_t d_ready = nullptr, d_done = nullptr;      // main: block-output gradient + its partial sums ready / s2: branch gradient written
   int init() {
     if (s) return MMSKIN_OK;
     int least = 0, greatest = 0;
@@ -64,12 +67,19 @@ struct SideStream {
     HIP_CHECK_RET(hipEventCreateWithFlags(&f_ready, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&f_done, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&f_staged, hipEventDisableTiming));
+    HIP_CHECK_RET(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&d_ready, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&d_done, hipEventDisableTiming));
     return MMSKIN_OK;
   }
   void destroy() {
     if (!s) return;
     for (int i = 0; i < 3; ++i) { (void)hipEventDestroy(ready[i]); (void)hipEventDestroy(done[i]); }
     (void)hipEventDestroy(f_ready); (void)hipEventDestroy(f_done); (void)hipEventDestroy(f_staged);
+    if (d_ready) (void)hipEventDestroy(d_ready);
+    if (d_done) (void)hipEventDestroy(d_done);
+    if (s2) (void)hipStreamDestroy(s2);
+    s2 = nullptr;
     (void)hipStreamDestroy(s);
     s = nullptr;
   }
