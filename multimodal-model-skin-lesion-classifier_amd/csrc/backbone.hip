@@ -437,7 +437,9 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   const bool use_side = !side_off && !p.prof.on;
   if (use_side && (rc = p.side.init())) return rc;
   for (int i = 0; i < 3; ++i) p.side.done_valid[i] = false;
-  static const bool ds_stream = [] { const char* v = getenv("MMSKIN_BWD_DS_STREAM"); return !v || atoi(v) != 0; }();
+  // measured: 19.99 / 20.06 ms per step off, 20.05 / 20.12 ms on (same box, profiles/r03_experiments.txt (9)) -- the chip has no idle
+  // resource for the branch to use, the launches only move.  Off by default; kept as an A/B knob.
+  static const bool ds_stream = [] { const char* v = getenv("MMSKIN_BWD_DS_STREAM"); return v && atoi(v) != 0; }();
   T* DX[3] = {S[2], S[6], S[5]};
   // main stream may overwrite buffer i only after the wgrad that reads it has finished
   auto acquire = [&](int i) -> int {
@@ -478,8 +480,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     T* dXd = DX[2];
     const bool has_ds = b.ds >= 0;
     // The downsample branch (BatchNorm-backward apply, dgrad) only has to be done when conv1's dgrad takes its result as the
-    // addend: it runs on its own stream beside conv3 .. conv2 (as in the forward) -- ~0.9 ms of launches per ResNet-50 step that
-    // sat on the main chain.  The main stream hands it g + partial_b (d_ready) and takes gin back (d_done).
+    // addend: with MMSKIN_BWD_DS_STREAM=1 it runs on its own stream beside conv3 .. conv2 (as in the forward; ~0.9 ms of launches
+    // per ResNet-50 step leave the main chain).  The main stream hands it g + partial_b (d_ready) and takes gin back (d_done).
     const bool ds_branch = has_ds && use_side && ds_stream && fused_ready;
     const T* dz_final;   // masked gradient of the block output (residual branch addend)
     dxi ^= 1;
