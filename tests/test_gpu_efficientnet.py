@@ -42,30 +42,41 @@ def test_efficientnet_eval_features_fp32(name, hw):
 
 @pytest.mark.parametrize("name", ["efficientnet-b0", "efficientnet-b7"])
 def test_efficientnet_train_step_vs_oracle_fp32(name):
-    """Stochastic depth off (p = 0, as dropout in every parity test): features, BN running statistics and every
-    gradient against the fp64 oracle, at most 3x the CPU fp32 oracle's own distance."""
+    """Stochastic depth off (p = 0, as dropout in every parity test): features, BN running statistics and every gradient.
+    B0: against the fp64 oracle, at most 3x the CPU fp32 oracle's own distance (noise-aware, as test_resnet_end_to_end_vs_oracle).
+    B7: against the CPU fp32 oracle with fixed bounds -- its fp64 oracle step alone took 100 s on the GPU box's host (8 s in the build
+    container) and the two fp32 runs sit 1.2e-4 (features) / 6e-4 (median gradient) from that truth, so they are bounded at 1e-3 /
+    5e-3 / 1e-2 (features / median / 90th percentile of the per-parameter relative L2) against each other."""
     cpu, hip = _pair(name, "fp32")
-    truth = det_init_(OracleEfficientNet(name)).double()
-    N = 4
+    b0 = name.endswith("b0")
+    truth = det_init_(OracleEfficientNet(name)).double() if b0 else None
+    N = 4 if b0 else 2
     x = det_tensor("eff.img", (N, 3, 64, 64))
     w = det_tensor("eff.w", (N, cpu.num_features))
     outs, grads = {}, {}
-    for nm, m, xi, wi in (("cpu", cpu, x, w), ("truth", truth, x.double(), w.double()), ("hip", hip, x.to(DEV), w.to(DEV))):
+    runs = [("cpu", cpu, x, w), ("hip", hip, x.to(DEV), w.to(DEV))] + ([("truth", truth, x.double(), w.double())] if b0 else [])
+    for nm, m, xi, wi in runs:
         m.train(); disable_dropout(m)
         f = m(xi)
         (f * wi).sum().backward()
         outs[nm] = f.detach().cpu().double()
         grads[nm] = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
-    assert set(grads["hip"]) == set(grads["truth"])
+    ref = "truth" if b0 else "cpu"
+    assert set(grads["hip"]) == set(grads[ref])
     assert all(torch.isfinite(g).all() for g in grads["hip"].values())
-    keys = list(grads["truth"])
-    f_hip, f_cpu = _l2(outs["hip"], outs["truth"]), _l2(outs["cpu"], outs["truth"])
-    cpu_l2 = sorted(_l2(grads["cpu"][k], grads["truth"][k]) for k in keys)
-    hip_l2 = sorted(_l2(grads["hip"][k], grads["truth"][k]) for k in keys)
-    print(name, "feat", f_hip, f_cpu, "grad median", hip_l2[len(keys) // 2], cpu_l2[len(keys) // 2], "p90", hip_l2[int(len(keys) * 0.9)], cpu_l2[int(len(keys) * 0.9)])
-    assert f_hip < 3 * f_cpu + 1e-4, (f_hip, f_cpu)
-    assert hip_l2[len(keys) // 2] <= 3 * cpu_l2[len(keys) // 2] + 1e-4
-    assert hip_l2[int(len(keys) * 0.9)] <= 3 * cpu_l2[int(len(keys) * 0.9)] + 1e-3
+    keys = list(grads[ref])
+    f_hip = _l2(outs["hip"], outs[ref])
+    hip_l2 = sorted(_l2(grads["hip"][k], grads[ref][k]) for k in keys)
+    if b0:
+        f_cpu = _l2(outs["cpu"], outs["truth"])
+        cpu_l2 = sorted(_l2(grads["cpu"][k], grads["truth"][k]) for k in keys)
+        print(name, "feat", f_hip, f_cpu, "grad median", hip_l2[len(keys) // 2], cpu_l2[len(keys) // 2], "p90", hip_l2[int(len(keys) * 0.9)], cpu_l2[int(len(keys) * 0.9)])
+        assert f_hip < 3 * f_cpu + 1e-4, (f_hip, f_cpu)
+        assert hip_l2[len(keys) // 2] <= 3 * cpu_l2[len(keys) // 2] + 1e-4
+        assert hip_l2[int(len(keys) * 0.9)] <= 3 * cpu_l2[int(len(keys) * 0.9)] + 1e-3
+    else:
+        print(name, "feat", f_hip, "grad median", hip_l2[len(keys) // 2], "p90", hip_l2[int(len(keys) * 0.9)])
+        assert f_hip < 1e-3 and hip_l2[len(keys) // 2] < 5e-3 and hip_l2[int(len(keys) * 0.9)] < 1e-2, (f_hip, hip_l2[len(keys) // 2], hip_l2[int(len(keys) * 0.9)])
     bn_c = [m for m in cpu.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     bn_h = [m for m in hip.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     assert rel_err(bn_h[-1].running_var, bn_c[-1].running_var) < 1e-3 and rel_err(bn_h[10].running_mean, bn_c[10].running_mean) < 1e-3
