@@ -56,7 +56,7 @@ struct DensePlan : PlanBase {
   std::vector<DBlock> blocks;
   DTrans trans[3];
   BNRef n5; size_t coef5_off, y5_off;
-  size_t off_wf, off_wd, off_stat, off_partial, off_coefbwd, off_dwv, off_red, off_slab;
+  size_t off_wf, off_wd, off_stat, off_partial, off_coefbwd, off_defer, off_dwv, off_red, off_slab;
   size_t off_sB, off_sB2, off_sU, off_sA, off_sA2, off_sX, off_sZ, off_sC;
   size_t stat_bytes = 0;
   // weight-gradient GEMMs on the side stream: slots 0/1 = conv2 operand (sB) of even/odd layers, 2/3 = conv1
@@ -236,6 +236,7 @@ int build_dense_plan(DensePlan& p) {
   p.off_stat = carve(cur, 2 * p.stat_bytes);
   p.off_partial = carve(cur, partial_bytes);
   p.off_coefbwd = carve(cur, 3 * (size_t)maxC * sizeof(float));
+  p.off_defer = carve(cur, 2 * (size_t)maxC * sizeof(float));   // per block: running sums of the consumers' cB / cC (backward)
   p.off_dwv = carve(cur, 64 * 256 * sizeof(float));
   p.off_red = carve(cur, bn_reduce_scratch_bytes(maxC));
   p.off_slab = carve(cur, slab);
@@ -447,11 +448,19 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
     if (rc) return rc;
   }
 
+  // Every later layer of a block adds cA*g + cB*x + cC to the channel prefix it consumed, and x (the concatenated activation) is the
+  // same tensor for all of them: the x / constant terms are summed as COEFFICIENTS (sB, sC: bn_bwd_finalize adds into them) and
+  // applied once, when a channel's gradient is consumed (its own layer's slice, or the block input at the block's end) -- the
+  // per-layer pass then reads g and read-modify-writes dcat only (3 passes over the prefix instead of 4).  MMSKIN_DN_DEFER=0: the old form.
+  static const bool defer = [] { const char* v = getenv("MMSKIN_DN_DEFER"); return !v || atoi(v) != 0; }();
+  float* sB_ = reinterpret_cast<float*>(ws + p.off_defer);
   for (int bi = 3; bi >= 0; --bi) {
     DBlock& b = p.blocks[bi];
     const T* cat = reinterpret_cast<const T*>(ws + b.cat_off);
     T* dcat = reinterpret_cast<T*>(ws + b.dcat_off);
     const double count = (double)b.rows;
+    float* sC_ = sB_ + b.Ctot;
+    if (defer) HIP_CHECK_RET(hipMemsetAsync(sB_, 0, 2 * (size_t)b.Ctot * sizeof(float), st));
     for (int li = (int)b.layers.size() - 1; li >= 0; --li) {
       DLayer& l = b.layers[li];
       float* k1 = reinterpret_cast<float*>(ws + l.coef1_off);
@@ -465,7 +474,11 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       T* sA = sAq[q];
       // gradient of this layer's 32 output channels, padded to the GEMM's 64
       if ((rc = acquire(q))) return rc;
-      PROF(K_BN_BWD, 0.0, 2.0 * b.rows * GROWTH * sizeof(T), slice_pack<T>(dcat + l.Cin, b.Ctot, GROWTH, G_PAD, b.rows, nullptr, nullptr, sB, st));
+      if (defer)
+        PROF(K_BN_BWD, 0.0, 3.0 * b.rows * GROWTH * sizeof(T),
+             slice_pack_deferred<T>(dcat + l.Cin, cat + l.Cin, b.Ctot, GROWTH, G_PAD, b.rows, sB_ + l.Cin, sC_ + l.Cin, sB, st));
+      else
+        PROF(K_BN_BWD, 0.0, 2.0 * b.rows * GROWTH * sizeof(T), slice_pack<T>(dcat + l.Cin, b.Ctot, GROWTH, G_PAD, b.rows, nullptr, nullptr, sB, st));
       // conv2: weight gradient (first 32 rows are real) and data gradient with norm2's mask + sums fused
       if ((rc = wgrad_async(q, c2, conv_flops(c2) / 2, sB, u, grads + l.w2_off, GROWTH, 0))) return rc;
       DgradFuse f2;
@@ -492,14 +505,22 @@ int dense_backward(DensePlan& p, const float* dfeat, const float* params, unsign
       {
         float* cB = cA + l.Cp; float* cC = cA + 2 * l.Cp;
         p.prof.begin(K_BN_BWD, st);
-        rc = bn_bwd_finalize(partial, f1.rows_written, l.Cp, count, k1 + 4 * l.Cp, k1 + 2 * l.Cp, k1 + 3 * l.Cp,
-                             grads + l.n1.g_off, grads + l.n1.b_off, cA, cB, cC, red, st, l.Cin);
-        if (!rc) rc = slice_bn_bwd_accumulate<T>(dcat, cat, b.Ctot, l.Cin, sZ, l.Cp, cA, cB, cC, b.rows, st);
+        if (defer) {   // padded channels [Cin, Cp) have gamma = 0: they add zeros to sB / sC
+          rc = bn_bwd_finalize(partial, f1.rows_written, l.Cp, count, k1 + 4 * l.Cp, k1 + 2 * l.Cp, k1 + 3 * l.Cp,
+                               grads + l.n1.g_off, grads + l.n1.b_off, cA, sB_, sC_, red, st, l.Cin, true);
+          if (!rc) rc = slice_accumulate_scaled<T>(dcat, b.Ctot, l.Cin, sZ, l.Cp, cA, b.rows, st);
+        } else {
+          rc = bn_bwd_finalize(partial, f1.rows_written, l.Cp, count, k1 + 4 * l.Cp, k1 + 2 * l.Cp, k1 + 3 * l.Cp,
+                               grads + l.n1.g_off, grads + l.n1.b_off, cA, cB, cC, red, st, l.Cin);
+          if (!rc) rc = slice_bn_bwd_accumulate<T>(dcat, cat, b.Ctot, l.Cin, sZ, l.Cp, cA, cB, cC, b.rows, st);
+        }
         p.prof.end(st);
-        if (p.prof.on) p.prof.bytes[K_BN_BWD] += 4.0 * b.rows * l.Cin * sizeof(T);
+        if (p.prof.on) p.prof.bytes[K_BN_BWD] += (defer ? 3.0 : 4.0) * b.rows * l.Cin * sizeof(T);
         if (rc) return rc;
       }
     }
+    if (defer)   // the block-input channels [0, C0): every layer of the block consumed them
+      PROF(K_BN_BWD, 0.0, 3.0 * b.rows * b.C0 * sizeof(T), slice_affine_inplace<T>(dcat, cat, b.Ctot, b.C0, b.rows, sB_, sC_, st));
     if (bi > 0) {
       // transition bi-1: avgpool <- conv 1x1 <- relu <- norm; writes the whole of the previous block's dcat
       DTrans& tr = p.trans[bi - 1];

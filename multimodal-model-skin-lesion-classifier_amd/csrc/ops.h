@@ -41,7 +41,8 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
 // n_grad (default C): dgamma / dbeta are written for channels < n_grad only (zero-padded channel tails)
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad = -1);
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad = -1,
+                    bool accumulate_bc = false);   // accumulate_bc: cB / cC are ADDED to (running sums over the consumers of one input)
 // dx = cA*dz + cB*x + cC ; optionally also writes dz (masked dy) to dz_out
 template <typename T>
 int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,
@@ -114,6 +115,13 @@ int slice_scatter(const T* src, int srcC, int C, T* dst, int pitch, size_t rows,
 template <typename T>
 int slice_bn_bwd_accumulate(T* dcat, const T* x, int pitch, int C, const T* dz, int Cp, const float* cA,
                             const float* cB, const float* cC, size_t rows, hipStream_t st);
+// deferred form (DenseNet): the x / constant terms of all consumers of a channel are added once, when its gradient is consumed
+template <typename T>
+int slice_accumulate_scaled(T* dcat, int pitch, int C, const T* dz, int Cp, const float* cA, size_t rows, hipStream_t st);
+template <typename T>
+int slice_pack_deferred(const T* d, const T* x, int pitch, int C, int Cp, size_t rows, const float* sB, const float* sC, T* out, hipStream_t st);
+template <typename T>
+int slice_affine_inplace(T* d, const T* x, int pitch, int C, size_t rows, const float* sB, const float* sC, hipStream_t st);
 // column partial sums of x[r*pitch + c], c < C -> stat_sum/stat_sq [nrows][C]
 template <typename T>
 int slice_stats(const T* x, int pitch, int C, size_t rows, float* stat_sum, float* stat_sq, int* nrows_out,

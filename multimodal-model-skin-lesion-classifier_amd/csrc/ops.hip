@@ -439,7 +439,7 @@ template <typename IN, int RL = 4>
 __global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                       float* cA, float* cB, float* cC, int n_grad) {
+                                       float* cA, float* cB, float* cC, int n_grad, int acc_bc) {
   __shared__ double red[2][RL][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -468,27 +468,29 @@ __global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __re
     if (dbeta && c < n_grad) dbeta[c] = (float)s1;
     double A = g * is;
     cA[c] = (float)A;
-    cB[c] = (float)(-A * is * dg / count);
-    cC[c] = (float)(A * (-s1 / count + mu * is * dg / count));
+    const float vb = (float)(-A * is * dg / count), vc = (float)(A * (-s1 / count + mu * is * dg / count));
+    if (acc_bc) { cB[c] += vb; cC[c] += vc; }   // running sums over the consumers of a shared input (DenseNet's deferred x / constant terms)
+    else { cB[c] = vb; cC[c] = vc; }
   }
 }
 
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad) {
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad, bool accumulate_bc) {
   if (n_grad < 0) n_grad = C;
+  const int acc_bc = accumulate_bc ? 1 : 0;
   if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
   } else if (nrows > 64) {
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
   }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -1127,6 +1129,81 @@ int slice_bn_bwd_accumulate(T* dcat, const T* x, int pitch, int C, const T* dz, 
   return MMSKIN_OK;
 }
 
+// Deferred form of the accumulation above (DenseNet: every later layer of a block adds cA*g + cB*x + cC to the prefix it consumed;
+// x is the SAME for all of them, so sum(cB) * x + sum(cC) is added once, when a channel's gradient is consumed):
+//   slice_accumulate_scaled : dcat[r*pitch + c] += cA[c] * dz[r*Cp + c]                        (no read of x: 3 passes instead of 4)
+//   slice_pack_deferred     : out[r][c < C] = d[r*pitch + c] + sB[c] * x[r*pitch + c] + sC[c], zero for C <= c < Cp
+//   slice_affine_inplace    : d[r*pitch + c] += sB[c] * x[r*pitch + c] + sC[c]                  for c < C
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void slice_accumulate_scaled_kernel(T* __restrict__ dcat, int pitch, unsigned CPR, const T* __restrict__ dz,
+                                                                          int Cp, const float* __restrict__ cA, size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const unsigned r = (unsigned)(i / CPR);
+    const int c0 = (int)(i - (size_t)r * CPR) * EPC;
+    const size_t off = (size_t)r * pitch + c0;
+    Chunk<T> g, dv;
+    g.load(dcat + off);
+    dv.load(dz + (size_t)r * Cp + c0);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g.v[e] += cA[c0 + e] * dv.v[e];
+    g.store(dcat + off);
+  }
+}
+template <typename T>
+int slice_accumulate_scaled(T* dcat, int pitch, int C, const T* dz, int Cp, const float* cA, size_t rows, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && Cp % EPC == 0 && pitch % EPC == 0 && C <= Cp && C <= pitch && rows < ((size_t)1 << 32), "slice_accumulate_scaled: C=%d Cp=%d pitch=%d", C, Cp, pitch);
+  const size_t nch = rows * (C / EPC);
+  hipLaunchKernelGGL(slice_accumulate_scaled_kernel<T>, dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, dcat, pitch, (unsigned)(C / EPC), dz, Cp, cA, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T, bool INPLACE>
+__global__ __launch_bounds__(EW_BLOCK) void slice_deferred_kernel(T* __restrict__ d, const T* __restrict__ x, int pitch, unsigned CPRin, unsigned CPRout,
+                                                                 const float* __restrict__ sB, const float* __restrict__ sC, T* __restrict__ out,
+                                                                 size_t nchunks) {
+  constexpr int EPC = DT<T>::EPC;
+  for (size_t i = blockIdx.x * (size_t)EW_BLOCK + threadIdx.x; i < nchunks; i += (size_t)gridDim.x * EW_BLOCK) {
+    const unsigned r = (unsigned)(i / CPRout);
+    const unsigned cc = (unsigned)(i - (size_t)r * CPRout);
+    const int c0 = (int)cc * EPC;
+    Chunk<T> v;
+    if (cc < CPRin) {
+      Chunk<T> xv;
+      v.load(d + (size_t)r * pitch + c0);
+      xv.load(x + (size_t)r * pitch + c0);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] += sB[c0 + e] * xv.v[e] + sC[c0 + e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v.v[e] = 0.f;
+    }
+    if (INPLACE) v.store(d + (size_t)r * pitch + c0);
+    else v.store(out + i * EPC);
+  }
+}
+template <typename T>
+int slice_pack_deferred(const T* d, const T* x, int pitch, int C, int Cp, size_t rows, const float* sB, const float* sC, T* out, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && Cp % EPC == 0 && pitch % EPC == 0 && C <= Cp && rows < ((size_t)1 << 32), "slice_pack_deferred: C=%d Cp=%d pitch=%d", C, Cp, pitch);
+  const size_t nch = rows * (Cp / EPC);
+  hipLaunchKernelGGL((slice_deferred_kernel<T, false>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, const_cast<T*>(d), x, pitch, (unsigned)(C / EPC),
+                     (unsigned)(Cp / EPC), sB, sC, out, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+template <typename T>
+int slice_affine_inplace(T* d, const T* x, int pitch, int C, size_t rows, const float* sB, const float* sC, hipStream_t st) {
+  constexpr int EPC = DT<T>::EPC;
+  ARG_CHECK(C % EPC == 0 && pitch % EPC == 0 && C <= pitch && rows < ((size_t)1 << 32), "slice_affine_inplace: C=%d pitch=%d", C, pitch);
+  const size_t nch = rows * (C / EPC);
+  hipLaunchKernelGGL((slice_deferred_kernel<T, true>), dim3(ew_grid(nch)), dim3(EW_BLOCK), 0, st, d, x, pitch, (unsigned)(C / EPC), (unsigned)(C / EPC),
+                     sB, sC, (T*)nullptr, nch);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void slice_stats_kernel(const T* __restrict__ x, int pitch, size_t rows, int C,
                                                           ColGeom g, float* partial_sum, float* partial_sq) {
@@ -1308,6 +1385,9 @@ int avgpool2_bwd(const T* dpool, int pitch, int N, int H, int W, int C, T* dx, h
   template int slice_scatter<T>(const T*, int, int, T*, int, size_t, hipStream_t);                                \
   template int slice_bn_bwd_accumulate<T>(T*, const T*, int, int, const T*, int, const float*, const float*,      \
                                           const float*, size_t, hipStream_t);                                     \
+  template int slice_accumulate_scaled<T>(T*, int, int, const T*, int, const float*, size_t, hipStream_t);       \
+  template int slice_pack_deferred<T>(const T*, const T*, int, int, int, size_t, const float*, const float*, T*, hipStream_t); \
+  template int slice_affine_inplace<T>(T*, const T*, int, int, size_t, const float*, const float*, hipStream_t); \
   template int slice_stats<T>(const T*, int, int, size_t, float*, float*, int*, hipStream_t);                     \
   template int avgpool2_fwd<T>(const T*, int, int, int, int, T*, int, hipStream_t);                               \
   template int avgpool2_bwd<T>(const T*, int, int, int, int, int, T*, hipStream_t);
