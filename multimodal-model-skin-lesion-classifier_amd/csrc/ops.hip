@@ -927,13 +927,16 @@ __global__ __launch_bounds__(EW_BLOCK) void stage_weights_kernel(const StageDesc
       for (int e = 0; e < EPC; ++e) v.v[e] = (o < d.Cout && c0 + e < d.Cin) ? s0[(size_t)e * d.taps] * fold : 0.f;
       v.store(wfwd + d.fwd_off + (size_t)i * EPC);
     } else {                       // dst [c][t][o0..o0+EPC)
-      const int opr = Cop / EPC;
-      int o0 = (i % opr) * EPC, ct = i / opr;
-      int t = ct % d.taps, c = ct / d.taps;
-      const float* s0 = src + ((size_t)o0 * d.Cin + c) * d.taps + t;
+      // consecutive lanes walk (c, t) -- the SOURCE's contiguous index inside a row o -- so each of the EPC loads of a wave is one
+      // coalesced run; with lanes along o every 4-byte read pulled its own 128-byte line (1.0 GB of HBM reads per step for 102 MB of
+      // parameters, profiles/r03_step_traffic.txt).  The stores become 16-byte pieces Cop elements apart: 4x their bytes at worst.
+      const int ctn = Cip * d.taps;
+      const int ct = i % ctn, o0 = (i / ctn) * EPC;
+      const int t = ct % d.taps, c = ct / d.taps;
+      const float* s0 = src + (size_t)o0 * CT + (size_t)c * d.taps + t;
 #pragma unroll
       for (int e = 0; e < EPC; ++e) v.v[e] = (c < d.Cin && o0 + e < d.Cout) ? s0[(size_t)e * CT] : 0.f;
-      v.store(wdgrad + d.dgrad_off + (size_t)i * EPC);
+      v.store(wdgrad + d.dgrad_off + (size_t)ct * Cop + o0);
     }
   }
 }
