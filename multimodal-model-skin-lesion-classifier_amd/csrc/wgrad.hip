@@ -670,6 +670,11 @@ static bool wgrad3_plan(const ConvShape& s, Wgrad3Args& a) {
   const int tiles = a.nblk_o * a.nblk_c;
   static const int target = env_int("MMSKIN_WGRAD3_BLOCKS", 512);      // one round of 2 workgroups per CU
   int ns = target / tiles > 0 ? target / tiles : 1;
+  // every split writes a whole 64 x 9 x 64 fp32 tile (147 KB) and the reduction reads it back: a split should multiply at least
+  // ~16 stages before it does.  DenseNet's 32-channel conv2 at 14^2 / 7^2 had 4 / 1 stages per split -- 6.2 GB of slab writes and
+  // most of 7.9 GB of reduction reads per step (profiles/r03_step_traffic_densenet169-metablock.txt); ResNet-50's 3x3 layers have 28 - 32.
+  static const int min_stages = env_int("MMSKIN_WGRAD3_MIN_STAGES", 16);
+  if (min_stages > 1 && ns > a.total_stages / min_stages) ns = a.total_stages / min_stages > 0 ? a.total_stages / min_stages : 1;
   if (ns > a.total_stages) ns = a.total_stages;
   a.stages_per_split = ceil_div(a.total_stages, ns);
   a.nsplit = ceil_div(a.total_stages, a.stages_per_split);

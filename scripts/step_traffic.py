@@ -1,6 +1,7 @@
 """HBM bytes of ONE whole training step, every kernel, from the two PMC passes of scripts/pmc_traffic.py (FETCH_SIZE / WRITE_SIZE,
 separate passes, `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline`): which kernel classes move the step's bytes.
-Same units / gfx950 correction as pmc_traffic.py (KiB; FETCH_SIZE doubled).  usage: step_traffic.py pmc_f pmc_w out.txt"""
+Same units / gfx950 correction as pmc_traffic.py (KiB; FETCH_SIZE doubled).  usage: step_traffic.py pmc_f pmc_w out.txt [title]
+With a title (another workload): grouped by kernel name instead of the ResNet-50 classes."""
 import csv, glob, os, re, sys
 
 
@@ -33,6 +34,10 @@ def last_step(rows):
     return out
 
 
+TITLE = sys.argv[4] if len(sys.argv) > 4 else None
+if TITLE:
+    import re as _re
+    klass = lambda n: _re.sub(r"\(anonymous namespace\)::", "", _re.sub(r"^void ", "", n))[:70]
 f = last_step(load(sys.argv[1], "FETCH_SIZE"))
 w = last_step(load(sys.argv[2], "WRITE_SIZE"))
 agg = {}
@@ -41,10 +46,10 @@ for r in f:
 for r in w:
     a = agg.setdefault(klass(r["Kernel_Name"]), [0.0, 0.0, 0]); a[1] += float(r["Counter_Value"]) * 1024.0
 tot_r = sum(a[0] for a in agg.values()); tot_w = sum(a[1] for a in agg.values())
-lines = [f"HBM traffic of one ResNet-50 + crossattention training step (batch 256, bf16), rocprofv3 PMC, all kernels: read {tot_r / 1e9:.1f} GB + write {tot_w / 1e9:.1f} GB = {(tot_r + tot_w) / 1e9:.1f} GB",
+lines = [f"HBM traffic of one {TITLE or 'ResNet-50 + crossattention'} training step ({'per-GPU batch of the workload' if TITLE else 'batch 256'}, bf16), rocprofv3 PMC, all kernels: read {tot_r / 1e9:.1f} GB + write {tot_w / 1e9:.1f} GB = {(tot_r + tot_w) / 1e9:.1f} GB",
          f"  = {(tot_r + tot_w) / 6.3e12 * 1e3:.1f} ms at the 6.3 TB/s a streaming pass achieves (8 TB/s nominal: {(tot_r + tot_w) / 8e12 * 1e3:.1f} ms)",
-         f"{'class':42s} {'launches':>8s} {'read GB':>9s} {'write GB':>9s} {'share':>7s}"]
-for k, a in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
-    lines.append(f"{k:42s} {a[2]:8d} {a[0] / 1e9:9.2f} {a[1] / 1e9:9.2f} {100 * (a[0] + a[1]) / (tot_r + tot_w):6.1f}%")
+         f"{'class':72s} {'launches':>8s} {'read GB':>9s} {'write GB':>9s} {'share':>7s}"]
+for k, a in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:28]:
+    lines.append(f"{k:72s} {a[2]:8d} {a[0] / 1e9:9.2f} {a[1] / 1e9:9.2f} {100 * (a[0] + a[1]) / (tot_r + tot_w):6.1f}%")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
