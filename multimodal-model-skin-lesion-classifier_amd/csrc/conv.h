@@ -59,6 +59,8 @@ struct ConvGemmArgs {
   uint64_t in_bytes;   // size of the gather source in bytes (the pipelined kernel's buffer descriptor: reads past it return zeros); 0 = not set
   int bm_step;         // valid rows per row block (= the tile height except for the pipelined kernel's 196-of-224-row tiles); set by finish_classes
   int pipe_ok;         // the caller can take a row-block count that differs from ceil(rows / 128) (statistics slabs), so any tile height may be chosen
+  int group_m;         // > 1: tiles are ordered in groups of group_m row blocks x all column blocks, row block fastest (Linear GEMMs whose
+                       // weight matrix exceeds an XCD's 4 MB L2: the group's A rows stay resident while the weight streams through ONCE per group)
   int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
 #ifdef MMSKIN_ABLATE
   unsigned long long* stamps;   // in-kernel phase stamps (scripts/conv_stamps.py): [workgroup][8] s_memtime values, or null

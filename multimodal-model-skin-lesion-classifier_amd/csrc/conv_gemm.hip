@@ -86,7 +86,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8] = clock64();
 #endif
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mblk = tile / p.nblk_n, nblk = tile - mblk * p.nblk_n;
+  int mblk = tile / p.nblk_n, nblk = tile - mblk * p.nblk_n;
+  if (p.group_m > 1) {   // grouped order (see ConvGemmArgs::group_m); wave-uniform
+    const int gsz = p.group_m * p.nblk_n, g = tile / gsz, t = tile - g * gsz;
+    const int mg = g * p.group_m, gm = min(p.group_m, p.total_mblk - mg);
+    nblk = t / gm; mblk = mg + (t - nblk * gm);
+  }
   int ci = 0;
   for (int i = 1; i < p.ncls; ++i)
     if (mblk >= p.cls[i].mblk_start) ci = i;
@@ -752,7 +757,16 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   }
   int grid = a.total_mblk * a.nblk_n;
   if (grid == 0) return MMSKIN_OK;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, a);
+  // Linear GEMMs ({M, 1, 1, K, N} shapes) with a weight matrix larger than an XCD's L2: with column blocks fastest every row block
+  // streamed the whole weight through L2 again (BEiT fc1: 1.2 GB of L2 fills per launch for 60 MB of operands,
+  // profiles/r03_step_traffic_beitv2-large-bert-rgatt.txt); groups of 8 row blocks keep their A rows resident instead.
+  static const int gm_env = [] { const char* v = getenv("MMSKIN_GEMM_GROUP_M"); return v ? atoi(v) : 8; }();
+  ConvGemmArgs b = a;
+  b.group_m = 0;
+  if (gm_env > 1 && a.ncls == 1 && a.IH == 1 && a.IW == 1 && a.nblk_n >= 4 && (size_t)a.Cout * a.wrow * sizeof(T) > ((size_t)2 << 20) &&
+      a.total_mblk >= 2 * gm_env)
+    b.group_m = gm_env;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, b);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

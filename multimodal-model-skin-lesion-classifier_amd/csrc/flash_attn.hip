@@ -37,6 +37,7 @@ struct FlashArgs {
   float scale, drop_p;
   int causal;
   uint64_t seed, offset;
+  int xcd;      // 1: XCD-aware tile order (MMSKIN_FLASH_XCD)
   int ablate;   // -DMMSKIN_ABLATE builds only (scripts/flash_ablate.py): bit0 K / V global loads after tile 0, bit1 softmax VALU work, bit2 MFMAs, bit3 K / V LDS stores
 };
 
@@ -72,8 +73,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NB * KV_BYTES + 4 * 16 * PPITCH];
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
   unsigned char* Ps = smem + NB * KV_BYTES + wid * 16 * PPITCH;
-  const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * BQ;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (own L2 each), so the query tiles of one (batch, head) -- which
+  // all stream the same K / V -- landed on up to 8 XCDs and K / V were fetched once per XCD (BERT shape: 0.9 GB of L2 fills per launch for
+  // 0.3 GB of q, k, v; profiles/r03_step_traffic_beitv2-large-bert-rgatt.txt).  xcd_remap gives an XCD a contiguous run of tiles.
+  const int lin0 = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int lin = p.xcd ? xcd_remap(lin0, (int)(gridDim.x * gridDim.y)) : lin0;
+  const int bh = lin / (int)gridDim.x, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (lin - bh * (int)gridDim.x) * BQ;
   const int L = p.L;
 #ifdef MMSKIN_ABLATE
   const int abl = p.ablate;
@@ -303,6 +309,7 @@ int mmskin_flash_attention_forward(const void* q, const void* k, const void* v, 
   a.o_sb = strides12[9]; a.o_sh = strides12[10]; a.o_sl = strides12[11];
   a.scale = scale; a.drop_p = drop_p; a.causal = causal; a.seed = seed; a.offset = offset;
   a.ablate = 0;
+  { static const int xcd = [] { const char* e = getenv("MMSKIN_FLASH_XCD"); return e ? atoi(e) : 1; }(); a.xcd = xcd; }
 #ifdef MMSKIN_ABLATE
   { const char* e = getenv("MMSKIN_FLASH_ABLATE"); a.ablate = e ? atoi(e) : 0; }
 #endif
