@@ -119,6 +119,8 @@ double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, 
 /* number of conv / dgrad launches this process has sent to the 8-phase pipelined kernel (224 / 256-row tiles, csrc/conv_gemm.hip);
  * the parity tests assert through it that the kernel they mean to check is the one that ran */
 int64_t mmskin_conv_pipe_launches(void);
+/* launches of the ring weight-gradient kernel (wgrad_ring.hip) since load: tests assert the path they mean to cover ran */
+int64_t mmskin_wgrad_ring_launches(void);
 /* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */
 int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W);
 int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,

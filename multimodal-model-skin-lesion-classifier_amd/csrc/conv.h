@@ -85,6 +85,13 @@ struct WgradArgs {
   int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
 };
 
+// ring form of the weight-gradient GEMM (wgrad_ring.hip): tile = 64 wo x 64 wk, 8 waves, 8 / (wo wk) pixel groups per workgroup
+struct WgradRingPlan { int wo, wk, nsplit, mps; bool s1; };
+bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r);        // tile shape + split count from the GEMM dimensions alone (slab sizing)
+bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r);              // false: the shape stays on the register-staged kernel of wgrad.hip
+int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st);   // fills a.nsplit / m_per_split / nblk_*; the caller reduces the slabs
+int wgrad_ring_launch_count();
+
 // Inference epilogue (eval-mode BatchNorm folded into the conv): out = [relu](acc + bias[c] + addend)
 struct FwdFuse {
   const float* bias = nullptr;    // [Cout] fp32

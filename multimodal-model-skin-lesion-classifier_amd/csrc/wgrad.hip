@@ -437,6 +437,10 @@ template <typename T>
 static size_t slab_bytes(int M, int Cout, int Ktot, int ntaps) {
   int BO, BKK, ns, mps;
   wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps, ntaps);
+  if constexpr (sizeof(T) == 2) {   // the ring kernel (wgrad_ring.hip) splits differently
+    WgradRingPlan rp;
+    if (wgrad_ring_tile(M, Cout, Ktot, rp) && rp.nsplit > ns) ns = rp.nsplit;
+  }
   return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * Cout * Ktot * sizeof(float);
 }
 static size_t wgrad3_slab_bytes(const ConvShape& s);   // all-taps 3x3 path below
@@ -474,6 +478,14 @@ static int run_wgrad(WgradArgs& a, float* dw, int C_for_layout, int ntaps_for_la
   ARG_CHECK(a.Cout % 64 == 0 && a.Ktot % 64 == 0, "wgrad: Cout=%d Ktot=%d must be multiples of 64", a.Cout, a.Ktot);
   ARG_CHECK(a.C % DT<T>::EPC == 0, "wgrad: C=%d", a.C);
   ARG_CHECK(a.OW <= 240 && a.OH <= 240, "wgrad: output %dx%d too large for the 16-bit reciprocal pixel stepping", a.OH, a.OW);
+  if constexpr (sizeof(T) == 2) {
+    WgradRingPlan rp;
+    if (wgrad_ring_plan(a, rp)) {
+      int rc = wgrad_ring_launch(a, rp, st);
+      if (rc) return rc;
+      return reduce_slabs(a.slab, a.nsplit, a.Cout, a.Ktot, dw, C_for_layout, ntaps_for_layout, cout_valid, cin_valid, st);
+    }
+  }
   int BO, BKK;
   wgrad_plan(a.M, a.Cout, a.Ktot, WG<T>::MS, BO, BKK, a.nsplit, a.m_per_split, a.ntaps);
   a.ablate = 0;

@@ -1,0 +1,86 @@
+"""-m gpu: the ring weight-gradient kernel (csrc/wgrad_ring.hip: LDS-DMA ring with counted vmcnt, 8 waves, pixel groups reduced
+through LDS) against torch's conv2d weight gradient (the ATen op the reference reaches through loss.backward(), train_pad_20.py:112).
+
+Inputs are bf16-REPRESENTABLE, so the bf16 kernel multiplies exactly what the fp64 reference multiplies and the only difference left
+is the fp32 accumulation order: the bound is 1e-4 of the gradient's rms on the WORST element (measured ~2e-6), i.e. one dropped
+8-pixel fragment, one stale ring slot or one row taken from the neighbouring split fails it -- unlike the 5e-2 bf16 bound of
+test_gpu_kernels.py, which has to absorb operand rounding.  Every case asserts through mmskin_wgrad_ring_launches() that the ring
+kernel is what ran.  Measured errors go to gpurun_out/parity_report.jsonl."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import DEV, conv_backward, rel_err
+from mmskin import _lib
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+TOL = 1e-4
+
+CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, what
+    (2, 64, 14, 14, 256, 1, 1, 0, "256x64 tile, two pixel groups meet in LDS, ragged last iteration (392 = 6*64 + 8)"),
+    (2, 256, 14, 14, 64, 1, 1, 0, "Cout = 64: 64x256 tile, two groups"),
+    (2, 256, 9, 11, 128, 1, 1, 0, "128x256 tile (one group of 8 waves), odd sizes, ragged last stage"),
+    (3, 128, 10, 10, 256, 1, 1, 0, "256x128 tile"),
+    (2, 128, 12, 12, 128, 1, 1, 0, "128x128 tile, two groups"),
+    (24, 128, 14, 14, 256, 1, 1, 0, "17 splits, the last one short"),
+    (40, 64, 14, 14, 256, 1, 1, 0, "two-group tile over 14 splits"),
+    (2, 256, 14, 14, 512, 1, 2, 0, "stride-2 gather (downsample 1x1), 2 cout tiles x 2 k tiles"),
+    (3, 256, 15, 13, 256, 1, 2, 0, "stride-2 gather on odd sizes"),
+    (2, 128, 14, 14, 128, 3, 2, 1, "3x3 stride 2: nine taps, padding taps zero-filled by out-of-range offsets"),
+    (2, 128, 15, 13, 128, 3, 2, 1, "3x3 stride 2, odd sizes"),
+    (16, 128, 28, 28, 128, 3, 2, 1, "3x3 stride 2 over 6 splits that cross image boundaries"),
+    (2, 64, 12, 12, 256, 3, 2, 1, "Cin = 64: nine 64-wide k tiles, one tap each, 256x64 tiles"),
+]
+
+
+def _record(**kw):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(kw) + "\n")
+
+
+def _bf16_exact(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
+def test_ring_wgrad_matches_fp64_reference(case):
+    N, Cin, H, W, Cout, k, stride, pad, what = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(case[:8]))
+    x = _bf16_exact(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = _bf16_exact(torch.randn(N, Cout, OH, OW, generator=g))
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    F.conv2d(xr, wr, stride=stride, padding=pad).backward(dy.double())
+    n0 = lib.mmskin_wgrad_ring_launches()
+    _, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), stride, pad, "bf16")
+    assert lib.mmskin_wgrad_ring_launches() == n0 + 1, "ring kernel not selected"
+    err = rel_err(dw, wr.grad)
+    d = (dw.double().cpu() - wr.grad)
+    rms_err = float(d.pow(2).mean().sqrt())
+    worst_over_rms = float(d.abs().max()) / (rms_err + 1e-30)
+    _record(test="wgrad_ring", case=list(case[:8]), what=what, max_err_over_rms=err, worst_over_rms_err=worst_over_rms)
+    assert err < TOL, (what, err)
+
+
+def test_ring_wgrad_is_bit_identical_across_repeats():
+    """A race in the ring (a fragment read overtaking its DMA, a refill overtaking a read, the group reduction overtaking the drain of
+    the trailing pieces) shows as run-to-run differences: 100 launches of a multi-split two-group layer must give one result."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = _bf16_exact(torch.randn(64, 64, 28, 28, generator=g)).to(DEV)
+    dy = _bf16_exact(torch.randn(64, 256, 28, 28, generator=g)).to(DEV)
+    w = torch.zeros(256, 64, 1, 1, device=DEV)
+    n0 = lib.mmskin_wgrad_ring_launches()
+    _, ref = conv_backward(dy, x, w, 1, 0, "bf16")
+    assert lib.mmskin_wgrad_ring_launches() == n0 + 1
+    for i in range(100):
+        _, dw = conv_backward(dy, x, w, 1, 0, "bf16")
+        assert torch.equal(dw, ref), i
