@@ -121,6 +121,13 @@ double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, 
 int64_t mmskin_conv_pipe_launches(void);
 /* launches of the ring weight-gradient kernel (wgrad_ring.hip) since load: tests assert the path they mean to cover ran */
 int64_t mmskin_wgrad_ring_launches(void);
+/* Algebraic BatchNorm backward of an expanding 1x1 convolution x = conv(y, w) (csrc/abn.hip; bf16 operands): with
+ * dz = cA g + cB x + cC per channel, dy = dz w and dw = dz^T y are computed from g, y, w and the coefficients alone
+ * (dy = [g | y][cA w ; w^T diag(cB) w] + cC w, dw = cA (g^T y) + cB (w (y^T y)) + cC (x) colsum(y)): neither dz nor x is read.
+ * Replaces autograd's backward through nn.BatchNorm2d + nn.Conv2d of torchvision's Bottleneck.conv3 (train_pad_20.py:112). */
+int64_t mmskin_abn_workspace_bytes(int N, int Cw, int C4, int H, int W);
+int mmskin_abn_backward(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
+                        int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream);
 /* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */
 int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W);
 int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,

@@ -1,0 +1,92 @@
+// Algebraic BatchNorm backward for an expanding 1x1 convolution x = y W^T (w -> 4w channels, ResNet bottleneck conv3) followed by a
+// training-mode BatchNorm:  dz = cA (.) g + cB (.) x + cC  (g = masked gradient of the BatchNorm output, coefficients per channel from
+// bn_bwd_finalize).  Because x IS y W^T, neither the data gradient nor the weight gradient needs dz -- or x -- in memory:
+//     dy = dz W        = [g | y] [cA (.) W ; Q] + r          Q = W^T diag(cB) W  (w x w),   r = cC W          (one GEMM, K = 4w + w)
+//     dW = dz^T y      = cA (.) (g^T y) + cB (.) (W (y^T y)) + cC (x) colsum(y)                                (one GEMM + a w-deep fix-up)
+// so the BatchNorm-backward apply pass (read g, read x, write dz: three passes over the block's widest tensor) disappears and both
+// GEMMs read g directly (profiles/r04_experiments.txt).  Reference semantics: autograd through nn.BatchNorm2d + nn.Conv2d of
+// torchvision's Bottleneck under model.train() (train_pad_20.py:102,112).  bf16 mode only; W below is the bf16-rounded weight the
+// forward multiplied with, so that y W^T reproduces the forward's accumulators.
+#include "conv.h"
+#include "ops.h"
+
+__device__ __forceinline__ float abn_wb(float w) { return bf16_bits_to_f32(f32_to_bf16_bits(w)); }
+
+// grid = Cw blocks (one per input channel k), 256 threads.  wd [Cw][C4 + Cw] bf16, bias [Cw], coef_copy [3][C4].
+// The Q row of this k is a C4-deep sum per (k2): the 256 threads split it as (256 / Cw) parts x Cw columns with eight independent
+// loads in flight each (the first version gave every k2 one thread and one dependent load at a time: 75 us on the critical path).
+__global__ __launch_bounds__(256) void abn_prep_kernel(const float* __restrict__ W, const float* __restrict__ cA, const float* __restrict__ cB,
+                                                       const float* __restrict__ cC, int C4, int Cw, bf16_t* __restrict__ wd,
+                                                       float* __restrict__ bias, float* __restrict__ coef_copy) {
+  __shared__ float colk[1024];   // cB[o] * W[o][k]
+  __shared__ float red[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  bf16_t* row = wd + (size_t)k * (C4 + Cw);
+  float bsum = 0.f;
+  for (int o = tid; o < C4; o += 256) {
+    const float w = abn_wb(W[(size_t)o * Cw + k]);
+    row[o] = (bf16_t)f32_to_bf16_bits(cA[o] * w);
+    colk[o] = cB[o] * w;
+    bsum += cC[o] * w;
+  }
+  red[tid] = bsum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) bias[k] = red[0];
+  __syncthreads();
+  const int np = 256 / Cw, k2 = tid % Cw, part = tid / Cw;   // Cw in {64, 128, 256}
+  const int per = C4 / np, ob = part * per;
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  const float* wp = W + (size_t)ob * Cw + k2;
+  for (int o = 0; o < per; o += 4, wp += (size_t)4 * Cw) {
+    q0 += abn_wb(wp[0]) * colk[ob + o];
+    q1 += abn_wb(wp[Cw]) * colk[ob + o + 1];
+    q2 += abn_wb(wp[2 * Cw]) * colk[ob + o + 2];
+    q3 += abn_wb(wp[3 * Cw]) * colk[ob + o + 3];
+  }
+  red[tid] = (q0 + q1) + (q2 + q3);
+  __syncthreads();
+  if (part == 0) {
+    float q = red[k2];
+    for (int j = 1; j < np; ++j) q += red[j * Cw + k2];
+    row[C4 + k2] = (bf16_t)f32_to_bf16_bits(q);
+  }
+  if (k == 0)
+    for (int o = tid; o < C4; o += 256) { coef_copy[o] = cA[o]; coef_copy[C4 + o] = cB[o]; coef_copy[2 * C4 + o] = cC[o]; }
+}
+
+int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, int C4, int Cw, bf16_t* wd, float* bias, float* coef_copy,
+             hipStream_t st) {
+  ARG_CHECK((Cw == 64 || Cw == 128 || Cw == 256) && C4 <= 1024 && C4 % (4 * (256 / Cw)) == 0, "abn_prep: C4=%d Cw=%d", C4, Cw);
+  hipLaunchKernelGGL(abn_prep_kernel, dim3(Cw), dim3(256), 0, st, W, cA, cB, cC, C4, Cw, wd, bias, coef_copy);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// dW[o][k] = cA[o] S[o][k] + cB[o] sum_k' W[o][k'] Gm[k'][k] + cC[o] colsum[k];  S = [g^T y ; y^T y] as [C4 + gram rows][Cw]
+// grid = C4 blocks, Cw threads (Cw <= 256)
+__global__ void abn_wgrad_finalize_kernel(const float* __restrict__ S, const float* __restrict__ colsum, const float* __restrict__ W,
+                                          const float* __restrict__ coef, int C4, int Cw, float* __restrict__ dW) {
+  const int o = blockIdx.x, k = threadIdx.x;
+  const float* Gm = S + (size_t)C4 * Cw;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // Cw % 4 == 0
+  const float* wr = W + (size_t)o * Cw;
+  for (int k2 = 0; k2 < Cw; k2 += 4) {
+    t0 += abn_wb(wr[k2]) * Gm[(size_t)k2 * Cw + k];
+    t1 += abn_wb(wr[k2 + 1]) * Gm[(size_t)(k2 + 1) * Cw + k];
+    t2 += abn_wb(wr[k2 + 2]) * Gm[(size_t)(k2 + 2) * Cw + k];
+    t3 += abn_wb(wr[k2 + 3]) * Gm[(size_t)(k2 + 3) * Cw + k];
+  }
+  const float t = (t0 + t1) + (t2 + t3);
+  dW[(size_t)o * Cw + k] = coef[o] * S[(size_t)o * Cw + k] + coef[C4 + o] * t + coef[2 * C4 + o] * colsum[k];
+}
+
+int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st) {
+  ARG_CHECK(Cw <= 256, "abn_wgrad_finalize: Cw=%d", Cw);
+  hipLaunchKernelGGL(abn_wgrad_finalize_kernel, dim3(C4), dim3(Cw), 0, st, S, colsum, W, coef, C4, Cw, dW);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}

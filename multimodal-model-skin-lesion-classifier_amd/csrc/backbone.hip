@@ -20,6 +20,8 @@ struct Unit {  // conv + batch-norm
   size_t x_off;                  // raw conv output (bytes in workspace)
   size_t y_off;                  // post-activation output (bytes); for the last unit of a block = block output
   size_t coef_off;               // floats: scale, shift, mean, invstd (4*Cout)
+  bool abn = false;              // algebraic BatchNorm backward (abn.hip): expanding 1x1 conv3 of a bottleneck, bf16 plans
+  size_t abn_coef_off = 0;       // this unit's copy of cA | cB | cC (3*Cout floats) for the weight-gradient stream
   size_t rows() const { return (size_t)s.N * s.OH() * s.OW(); }
 };
 
@@ -41,6 +43,8 @@ struct Plan : PlanBase {
   // workspace layout (bytes)
   size_t off_img4, off_wf, off_wd, off_stat, off_pool, off_idx, off_scratch[7], off_slab, off_partial,
       off_coefbwd, off_coefbwd_b, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
+  size_t off_abn_wd = 0, off_abn_bias = 0, off_abn_S = 0, off_abn_cs = 0;   // algebraic BatchNorm backward scratch
+  size_t off_abn_wd2 = 0, off_abn_bias2 = 0;                                 // ... of a stride-1 downsample convolution (its folded weights live beside conv3's)
   size_t maxact_bytes = 0, stat_bytes = 0;
 
   int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
@@ -196,6 +200,40 @@ int build_plan(Plan& p) {
     b.mask_off = carve(cur, bl.rows() * bl.s.Cout * es / 16);
   }
   for (int i = 0; i < 7; ++i) p.off_scratch[i] = carve(cur, p.maxact_bytes);
+  {   // algebraic BatchNorm backward of the bottlenecks' expanding 1x1 convolutions (bf16 plans; MMSKIN_ABN=0 switches it off,
+      // MMSKIN_ABN_MAXC bounds the input width it takes: the data gradient of wider layers belongs to the pipelined kernel)
+    static const int abn_on = [] { const char* v = getenv("MMSKIN_ABN"); return v ? atoi(v) : 1; }();
+    static const int abn_maxc = [] { const char* v = getenv("MMSKIN_ABN_MAXC"); return v ? atoi(v) : 128; }();
+    size_t wd_max = 0, s_max = 0;
+    int cw_max = 0;
+    std::vector<int> cand;
+    for (Block& b : p.blocks) { cand.push_back(b.units.back()); if (b.ds >= 0) cand.push_back(b.ds); }
+    for (int ui : cand) {
+      Unit& u = p.units[ui];
+      WgradRingPlan rp;
+      int sh = 0;
+      while ((u.s.Cin << sh) < u.s.Cout) ++sh;
+      if (!abn_on || p.dtype != 1 || !bottleneck || u.s.kh != 1 || u.s.stride != 1 || u.s.Cin > abn_maxc || u.s.Cin % 64 || (u.s.Cin << sh) != u.s.Cout ||
+          !wgrad_gram_plan((int)u.rows(), u.s.Cout, u.s.Cin, rp) || rp.gram_tiles != 1)
+        continue;
+      u.abn = true;
+      u.abn_coef_off = carve(cur, 3 * (size_t)u.s.Cout * sizeof(float));
+      const size_t sb = wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin);
+      if (sb > slab_max) slab_max = sb;
+      const size_t wdb = (size_t)u.s.Cin * (u.s.Cout + u.s.Cin) * 2, sf = ((size_t)u.s.Cout + 64 * rp.wo) * u.s.Cin * sizeof(float);
+      if (wdb > wd_max) wd_max = wdb;
+      if (sf > s_max) s_max = sf;
+      if (u.s.Cin > cw_max) cw_max = u.s.Cin;
+    }
+    if (wd_max) {
+      p.off_abn_wd = carve(cur, wd_max);
+      p.off_abn_bias = carve(cur, (size_t)cw_max * sizeof(float));
+      p.off_abn_S = carve(cur, s_max);
+      p.off_abn_cs = carve(cur, (size_t)cw_max * sizeof(float));
+      p.off_abn_wd2 = carve(cur, wd_max);
+      p.off_abn_bias2 = carve(cur, (size_t)cw_max * sizeof(float));
+    }
+  }
   p.off_slab = carve(cur, slab_max);
   p.off_partial = carve(cur, partial_max);
   p.off_partial_b = carve(cur, partial_max);
@@ -410,6 +448,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   // BN backward of unit u when `dz` is ALREADY masked and its partial sums (sum dz, sum dz*x) were
   // produced by the epilogue of the dgrad launch that wrote dz: finalize + one apply pass.
   // on_branch: the downsample branch on its own stream (own coefficient and reduction scratch)
+  // dx == nullptr: finalize only (gamma / beta gradients and the coefficients cA, cB, cC) -- the algebraic path folds the apply
+  // into its two GEMMs
   auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx, bool on_branch = false) -> int {
     const int C = u.s.Cout;
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
@@ -421,9 +461,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     int r;
     p.prof.begin(K_BN_BWD, st);
     struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
-    if (p.prof.on) p.prof.bytes[K_BN_BWD] += 3.0 * u.rows() * C * sizeof(T);
+    if (p.prof.on && dx) p.prof.bytes[K_BN_BWD] += 3.0 * u.rows() * C * sizeof(T);
     if ((r = bn_bwd_finalize(part, nrows, C, (double)u.rows(), params + u.g_off, coef + 2 * C, coef + 3 * C,
                              grads + u.g_off, grads + u.b_off, kA, cB, cC, red, bs))) return r;
+    if (!dx) return MMSKIN_OK;
     return bn_bwd_apply<T>(dz, x, nullptr, coef, coef + C, MASK_NONE, kA, cB, cC, dx, nullptr, u.rows(), C, bs);
   };
 
@@ -466,6 +507,43 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     return MMSKIN_OK;
   };
   int dxi = 0;   // index of the buffer holding the current dX
+  for (int i = 0; i < 2; ++i) p.side.g_done_valid[i] = false;
+  // algebraic path: the weight-gradient stream reads the block-output gradient buffer (S[0] / S[1]) itself; the main stream may write
+  // that buffer again (two blocks later) only after that launch has finished
+  auto g_index = [&](const T* buf) { return buf == S[0] ? 0 : 1; };
+  auto g_acquire = [&](const T* buf, hipStream_t writer = nullptr) -> int {
+    const int i = g_index(buf);
+    if (use_side && p.side.g_done_valid[i]) HIP_CHECK_RET(hipStreamWaitEvent(writer ? writer : st, p.side.g_done[i], 0));
+    return MMSKIN_OK;
+  };
+  // dW = cA (.) (g^T y) + cB (.) (W (y^T y)) + cC (x) colsum(y) on the weight-gradient stream
+  auto wgrad_abn_async = [&](Unit& u, const T* gbuf, const T* uin) -> int {
+    if constexpr (sizeof(T) == 2) {
+      hipStream_t ws_st = st;
+      if (use_side) {
+        HIP_CHECK_RET(hipEventRecord(p.side.g_ready, st));
+        HIP_CHECK_RET(hipStreamWaitEvent(p.side.s, p.side.g_ready, 0));
+        ws_st = p.side.s;
+      }
+      float* S_out = reinterpret_cast<float*>(ws + p.off_abn_S);
+      float* cs_out = reinterpret_cast<float*>(ws + p.off_abn_cs);
+      p.prof.begin(K_WGRAD, st);
+      int r = launch_wgrad_gram(u.s.N, u.s.OH(), u.s.OW(), u.s.Cin, u.s.Cout, gbuf, uin, slab, S_out, cs_out, ws_st);
+      if (!r) r = abn_wgrad_finalize(S_out, cs_out, params + u.w_off, reinterpret_cast<const float*>(ws + u.abn_coef_off), u.s.Cout, u.s.Cin,
+                                     grads + u.w_off, ws_st);
+      p.prof.end(st);
+      if (p.prof.on) { p.prof.flops[K_WGRAD] += conv_flops(u.s); p.prof.bytes[K_WGRAD] += conv_bytes(u.s, sizeof(T)); }
+      if (r) return r;
+      if (use_side) {
+        const int gi = g_index(gbuf);
+        HIP_CHECK_RET(hipEventRecord(p.side.g_done[gi], p.side.s));
+        p.side.g_done_valid[gi] = true;
+      }
+      return MMSKIN_OK;
+    } else {
+      return MMSKIN_ERR_UNSUPPORTED;
+    }
+  };
 
   bool fused_ready = false;   // g already holds the masked dz of this block's final unit, partials in the slabs
   int fused_rows = 0;
@@ -488,6 +566,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     if ((rc = acquire(dxi))) return rc;
     if (has_ds && !ds_branch && (rc = acquire(2))) return rc;
     T* dX = DX[dxi];
+    const bool abn = fused_ready && ul.abn && sizeof(T) == 2;
     if (fused_ready) {
       if (ds_branch) {
         HIP_CHECK_RET(hipEventRecord(p.side.d_ready, st));
@@ -495,9 +574,24 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if (p.side.done_valid[2]) HIP_CHECK_RET(hipStreamWaitEvent(p.side.s2, p.side.done[2], 0));   // the last wgrad that read dXd
         if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd, true))) return rc;
       }
-      if ((rc = bn_backward_fused(ul, g, partial, fused_rows, dX))) return rc;
-      if (has_ds && !ds_branch)
-        if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd))) return rc;
+      if ((rc = bn_backward_fused(ul, g, partial, fused_rows, abn ? nullptr : dX))) return rc;
+      if (abn) {   // fold the coefficients into this block's conv3 data-gradient weights; keep a copy for the weight-gradient fix-up
+        if constexpr (sizeof(T) == 2) {
+          if ((rc = abn_prep(params + ul.w_off, cA, cA + ul.s.Cout, cA + 2 * ul.s.Cout, ul.s.Cout, ul.s.Cin, reinterpret_cast<bf16_t*>(ws + p.off_abn_wd),
+                             reinterpret_cast<float*>(ws + p.off_abn_bias), reinterpret_cast<float*>(ws + ul.abn_coef_off), st))) return rc;
+        }
+      }
+      if (has_ds && !ds_branch) {
+        Unit& d = p.units[b.ds];
+        const bool abn_d = d.abn && sizeof(T) == 2;
+        if ((rc = bn_backward_fused(d, g, partial_b, fused_rows, abn_d ? nullptr : dXd))) return rc;
+        if (abn_d) {
+          if constexpr (sizeof(T) == 2) {
+            if ((rc = abn_prep(params + d.w_off, cA, cA + d.s.Cout, cA + 2 * d.s.Cout, d.s.Cout, d.s.Cin, reinterpret_cast<bf16_t*>(ws + p.off_abn_wd2),
+                               reinterpret_cast<float*>(ws + p.off_abn_bias2), reinterpret_cast<float*>(ws + d.abn_coef_off), st))) return rc;
+          }
+        }
+      }
       dz_final = g;
     } else {
       if ((rc = bn_backward(ul, g, out, MASK_FROM_Y, dX, has_ds ? nullptr : dZ))) return rc;
@@ -508,7 +602,9 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     for (int i = nu - 1; i >= 0; --i) {
       Unit& u = p.units[b.units[i]];
       const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
-      if ((rc = wgrad_async(u, dxi, uin))) return rc;
+      const bool abn_u = abn && i == nu - 1;
+      if (abn_u) { if ((rc = wgrad_abn_async(u, g, uin))) return rc; }
+      else if ((rc = wgrad_async(u, dxi, uin))) return rc;
       if (i > 0) {
         // dgrad writes the gradient of unit i-1's ReLU output; its epilogue applies that ReLU's mask and
         // accumulates unit i-1's BN-backward sums, so the stand-alone reduce pass is gone.
@@ -516,6 +612,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         float* cup = reinterpret_cast<float*>(ws + up.coef_off);
         DgradFuse f;
         f.x = ws + up.x_off; f.scale = cup; f.shift = cup + up.s.Cout; f.partial = partial;
+        if (abn_u) {   // dY = [g | y] [cA (.) W ; Q] + r: no dz in memory
+          f.in2 = uin; f.k2 = u.s.Cin; f.bias = reinterpret_cast<const float*>(ws + p.off_abn_bias);
+          PROF(K_CONV_DGRAD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 1), launch_conv_dgrad<T>(u.s, g, reinterpret_cast<const T*>(ws + p.off_abn_wd), dY, (const T*)nullptr, st, &f));
+        } else
         PROF(K_CONV_DGRAD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 1), launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, dY, (const T*)nullptr, st, &f));
         dxi ^= 1;                              // the next dX goes to the other buffer: wgrad(u) may still read this one
         if ((rc = acquire(dxi))) return rc;
@@ -525,17 +625,24 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         const T* addend = dz_final;
         if (has_ds) {
           Unit& d = p.units[b.ds];
+          if ((rc = g_acquire(gin, ds_branch ? p.side.s2 : nullptr))) return rc;
           if (ds_branch) {
             if ((rc = wgrad_async(d, 2, in, p.side.s2))) return rc;
             if ((rc = launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, p.side.s2))) return rc;
             HIP_CHECK_RET(hipEventRecord(p.side.d_done, p.side.s2));
             HIP_CHECK_RET(hipStreamWaitEvent(st, p.side.d_done, 0));
+          } else if (fused_ready && d.abn && sizeof(T) == 2) {   // stride-1 downsample convolution on the algebraic path, as conv3 above
+            if ((rc = wgrad_abn_async(d, g, in))) return rc;
+            DgradFuse fd;
+            fd.in2 = in; fd.k2 = d.s.Cin; fd.bias = reinterpret_cast<const float*>(ws + p.off_abn_bias2);
+            PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, g, reinterpret_cast<const T*>(ws + p.off_abn_wd2), gin, (const T*)nullptr, st, &fd));
           } else {
             if ((rc = wgrad_async(d, 2, in))) return rc;
             PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
           }
           addend = gin;   // main-branch dgrad accumulates on top, in place
         }
+        if ((rc = g_acquire(gin))) return rc;
         DgradFuse f;
         DgradFuse* fp = nullptr;
         if (bi > 0) {   // gin is the gradient of the previous block's output: fuse that block's final BN reduce

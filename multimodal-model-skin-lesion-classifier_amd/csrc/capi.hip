@@ -319,6 +319,43 @@ double mmskin_conv2d_dgrad_time(int N, int Cin, int H, int W, int Cout, int kh, 
   return (double)ms * 1e3 / iters;
 }
 
+/* Algebraic BatchNorm backward of an expanding 1x1 convolution (abn.hip), op level: g [N,C4,H,W] is the (masked) gradient of the
+ * BatchNorm output, y [N,Cw,H,W] the convolution's input, w [C4,Cw] its weight, cA / cB / cC [C4] the BatchNorm-backward coefficients
+ * (dz = cA g + cB x + cC, x = conv(y)).  Returns dy = dz W [N,Cw,H,W] and dw = dz^T y [C4,Cw] without forming dz or x. */
+int64_t mmskin_abn_workspace_bytes(int N, int Cw, int C4, int H, int W) {
+  const size_t M = (size_t)N * H * W;
+  size_t b = 4096 + M * C4 * 2 + 2 * M * Cw * 2 + (size_t)Cw * (C4 + Cw) * 2 + 4 * (size_t)Cw + 12 * (size_t)C4;
+  b += wgrad_gram_slab_bytes((int)M, C4, Cw) + ((size_t)C4 + 256) * Cw * 4 + 16 * 256;
+  return (int64_t)b;
+}
+int mmskin_abn_backward(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
+                        int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Carver c(workspace);
+  const size_t M = (size_t)N * H * W;
+  ARG_CHECK(wgrad_gram_slab_bytes((int)M, C4, Cw) > 0, "abn_backward: shape C4=%d Cw=%d unsupported", C4, Cw);
+  bf16_t* gh = c.take<bf16_t>(M * C4);
+  bf16_t* yh = c.take<bf16_t>(M * Cw);
+  bf16_t* dyh = c.take<bf16_t>(M * Cw);
+  bf16_t* wd = c.take<bf16_t>((size_t)Cw * (C4 + Cw));
+  float* bias = c.take<float>(Cw);
+  float* coef = c.take<float>(3 * (size_t)C4);
+  float* S = c.take<float>(((size_t)C4 + 256) * Cw);
+  float* cs = c.take<float>(256);
+  float* slab = c.take<float>(wgrad_gram_slab_bytes((int)M, C4, Cw) / sizeof(float));
+  int rc;
+  if ((rc = nchw_to_nhwc<bf16_t>(g, N, C4, H, W, gh, st))) return rc;
+  if ((rc = nchw_to_nhwc<bf16_t>(y, N, Cw, H, W, yh, st))) return rc;
+  if ((rc = abn_prep(w, cA, cB, cC, C4, Cw, wd, bias, coef, st))) return rc;
+  ConvShape s = {N, H, W, Cw, C4, 1, 1, 1, 0};
+  DgradFuse f;
+  f.in2 = yh; f.k2 = Cw; f.bias = bias;
+  if ((rc = launch_conv_dgrad<bf16_t>(s, gh, wd, dyh, (const bf16_t*)nullptr, st, &f))) return rc;
+  if ((rc = nhwc_to_nchw<bf16_t>(dyh, N, Cw, H, W, dy, st))) return rc;
+  if ((rc = launch_wgrad_gram(N, H, W, Cw, C4, gh, yh, slab, S, cs, st))) return rc;
+  return abn_wgrad_finalize(S, cs, w, coef, C4, Cw, dw, st);
+}
+
 /* same for the weight-gradient kernel (+ its slab reduction) */
 double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,
                                 int iters, void* workspace, void* stream) {

@@ -61,6 +61,11 @@ struct ConvGemmArgs {
   int pipe_ok;         // the caller can take a row-block count that differs from ceil(rows / 128) (statistics slabs), so any tile height may be chosen
   int group_m;         // > 1: tiles are ordered in groups of group_m row blocks x all column blocks, row block fastest (Linear GEMMs whose
                        // weight matrix exceeds an XCD's 4 MB L2: the group's A rows stay resident while the weight streams through ONCE per group)
+  // ---- two-source A operand (algebraic BatchNorm backward of an expanding 1x1 convolution, backbone.hip): reduction indices
+  // [0, K1) come from `in` (row pitch Cpitch), [K1, C) from `in2` (row pitch Cpitch >> pitch2_shift).  simple_src launches of the
+  // 128-row kernels only.
+  const void* in2;
+  int K1, pitch2_shift;
   int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
 #ifdef MMSKIN_ABLATE
   unsigned long long* stamps;   // in-kernel phase stamps (scripts/conv_stamps.py): [workgroup][8] s_memtime values, or null
@@ -81,16 +86,29 @@ struct WgradArgs {
   int M, m_per_split, nsplit;
   int nblk_o, nblk_k;  // tiles over Cout / Ktot
   int simple1x1;       // host-side selector: 1x1 / stride 1 / no padding (gathered-input row m IS pixel m)
+  // ---- ring kernel only: Gram tiles (algebraic BatchNorm backward, backbone.hip).  Cout tiles ob >= nblk_o_main take their
+  // "dY" rows from the INPUT tensor instead (columns (ob - nblk_o_main) * BO .. of its first gram_cols channels, zeros beyond), so
+  // the launch also produces in^T in (slab rows Cout ..) and, through one extra MFMA against a ones fragment, the column sums of
+  // `in` (colsum[(split * G + group)][gram tile columns]).  nblk_o_main == nblk_o: plain weight gradient.
+  int nblk_o_main, gram_cols;
+  float* colsum;
   int ablate;          // timing experiments only: bit0 skip X loads, bit1 skip Y loads, bit2 skip MFMA+LDS reads, bit3 skip slab store, bit4 skip LDS writes
   int8_t offy[MMSKIN_MAX_TAPS], offx[MMSKIN_MAX_TAPS];
 };
 
 // ring form of the weight-gradient GEMM (wgrad_ring.hip): tile = 64 wo x 64 wk, 8 waves, 8 / (wo wk) pixel groups per workgroup
-struct WgradRingPlan { int wo, wk, nsplit, mps; bool s1; };
+struct WgradRingPlan { int wo, wk, nsplit, mps; bool s1; int gram_tiles; };
 bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r);        // tile shape + split count from the GEMM dimensions alone (slab sizing)
 bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r);              // false: the shape stays on the register-staged kernel of wgrad.hip
 int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st);   // fills a.nsplit / m_per_split / nblk_*; the caller reduces the slabs
 int wgrad_ring_launch_count();
+// dY^T in plus in^T in and colsum(in) in one launch (1x1 / stride 1 layers whose Cout x Cin the ring kernel tiles): the slab rows are
+// [Cout main | gram tile rows]; returns the plan through r, reduces the slabs into s_out [Cout + gram rows][Cin] and the column sums
+// into colsum_out [Cin].  scratch: wgrad_gram_scratch_floats() floats behind the caller's slab.
+bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r);
+size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin);
+int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, const bf16_t* in, float* slab, float* s_out, float* colsum_out,
+                      hipStream_t st);
 
 // Inference epilogue (eval-mode BatchNorm folded into the conv): out = [relu](acc + bias[c] + addend)
 struct FwdFuse {
@@ -126,6 +144,11 @@ struct DgradFuse {
   float* partial = nullptr;     // [rows][2][Cin]: sum dz, sum dz*x
   float* partial_b = nullptr;   // [rows][2][Cin]: sum dz, sum dz*x2
   int rows_written = 0;         // out: partial rows the launch produced
+  // second gradient-side operand (1x1 / stride 1 only): din = [dout | in2] x wt_staged^T + bias, where wt_staged rows are
+  // s.Cout + k2 long and in2 is [rows][k2] (k2 * 2^j = s.Cout)
+  const void* in2 = nullptr;
+  int k2 = 0;
+  const float* bias = nullptr;  // [Cin] fp32, added before the mask
 };
 int conv_dgrad_partial_rows(const ConvShape& s);
 
@@ -173,3 +196,8 @@ size_t stem_wgrad_slab_bytes(int N, int OH, int OW);
 template <typename T>
 int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout, const T* img4,
                            float* slab, float* dwv, hipStream_t st);
+
+// algebraic BatchNorm backward of an expanding 1x1 convolution (abn.hip)
+int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, int C4, int Cw, bf16_t* wd, float* bias, float* coef_copy,
+             hipStream_t st);
+int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st);

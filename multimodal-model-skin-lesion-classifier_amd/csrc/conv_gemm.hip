@@ -188,6 +188,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
     }
   }
   const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  const unsigned char* in2_b = reinterpret_cast<const unsigned char*>(p.in2);
+  const bool two_src = !PIPE && p.in2 != nullptr;
   const unsigned char* w_b = reinterpret_cast<const unsigned char*>(p.w) +
                              (size_t)(n0 + lr) * p.wrow * sizeof(T);
   const size_t w_pass = (size_t)PR * p.wrow * sizeof(T);
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       const int iy = a_iy[i] + oy, ix = a_ix[i] + ox;                                        \
       const bool ok = (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;            \
       const unsigned char* src = in_b + (int64_t)(a_base[i] + toff + c) * (int)sizeof(T);    \
+      if (two_src && c >= p.K1) src = in2_b + (int64_t)((a_base[i] >> p.pitch2_shift) + c - p.K1) * (int)sizeof(T); \
       GLDS16(ok ? src : zero_page, As + (buf) * A_BYTES + (PR * i + wid_u * 8) * 128);       \
     }                                                                                        \
     if (!(abl & 2)) _Pragma("unroll") for (int i = 0; i < BP; ++i)                           \
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   //   6 = 2 + layer scale, dropout and an fp32 residual stream                  (Linear layers of the frozen transformer encoders)
   constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5, HAS_BR = EPI == 1 || EPI == 2 || EPI == 6, HAS_MY = EPI == 1;
   constexpr bool HAS_TR = EPI == 6;
+  constexpr bool HAS_BIAS = HAS_BR || EPI == 3;   // profile 3 + bias: the algebraic BatchNorm-backward dgrad (constant row of the folded coefficients)
   constexpr bool HAS_MB = EPI == 1 || EPI == 4 || EPI == 5, HAS_X = EPI == 1 || EPI >= 3, HAS_X2 = EPI == 1 || EPI == 5;
   const unsigned char* add_b = HAS_ADD ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
   const unsigned char* my_b = HAS_MY ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   const unsigned char* ex_b = HAS_X ? reinterpret_cast<const unsigned char*>(p.ep_x) : nullptr;
   const unsigned char* ex2_b = HAS_X2 ? reinterpret_cast<const unsigned char*>(p.ep_x2) : nullptr;
   const bool mask_from_x = HAS_X && p.ep_scale != nullptr;
-  const bool has_bias = HAS_BR && p.ep_bias != nullptr;
+  const bool has_bias = HAS_BIAS && p.ep_bias != nullptr;
   const bool do_relu = HAS_BR && p.ep_relu == 1;
   const bool do_gelu = HAS_BR && p.ep_relu == 2;          // exact (erf) GELU: the MLP of the transformer blocks
   float* out_f32 = HAS_BR ? p.out_f32 : nullptr;         // Linear layers at the fp32 op boundary: widen while storing
@@ -801,7 +805,7 @@ static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, Pi
   static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
   static const int mintiles = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINTILES"); return v ? atoi(v) : 192; }();
   static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
-  if (!on || !a.pipe_ok || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
+  if (!on || !a.pipe_ok || a.in2 || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
       a.C % 64 != 0 || a.ncls < 1)
     return false;
   if (tr && (heavy || a.addend || a.stat_sum || !a.out_f32)) return false;   // the transformer-residual epilogue's own contract (checked below)
@@ -855,9 +859,9 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   static const int big_min_k = [] { const char* v = getenv("MMSKIN_GEMM_BIG_MINK"); return v ? atoi(v) : 2048; }();
   static const bool profiles_on = [] { const char* v = getenv("MMSKIN_CONV_EPI_PROFILES"); return !v || atoi(v) != 0; }();
   int prof = 1;
-  if (profiles_on && heavy && !a.ep_mask_y && !a.ep_bias && !a.ep_relu) {
-    if (a.ep_x && !a.addend && !a.ep_mask_bits && !a.ep_x2) prof = 3;
-    else if (a.ep_x && a.ep_mask_bits && !a.ep_scale) prof = a.ep_x2 ? 5 : 4;
+  if (profiles_on && heavy && !a.ep_mask_y && !a.ep_relu) {
+    if (a.ep_x && !a.addend && !a.ep_mask_bits && !a.ep_x2) prof = 3;   // (+ optional bias)
+    else if (!a.ep_bias && a.ep_x && a.ep_mask_bits && !a.ep_scale) prof = a.ep_x2 ? 5 : 4;
   }
   if constexpr (sizeof(T) == 2) {
     PipeChoice pc;
@@ -985,6 +989,15 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
   a.N = s.N; a.IH = s.OH(); a.IW = s.OW(); a.C = s.Cout; a.Cpitch = s.Cout;
   a.in_bytes = (uint64_t)s.N * s.OH() * s.OW() * s.Cout * sizeof(T);
   a.Cout = s.Cin; a.wrow = s.kh * s.kw * s.Cout;
+  if (fuse && fuse->in2) {
+    int sh = 0;
+    while ((fuse->k2 << sh) < s.Cout) ++sh;
+    ARG_CHECK(s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0 && fuse->k2 > 0 && (fuse->k2 << sh) == s.Cout && fuse->k2 % DT<T>::BK == 0 &&
+              s.Cout % DT<T>::BK == 0, "conv_dgrad: the second operand needs a 1x1 / stride 1 layer and k2 * 2^j == Cout (k2=%d Cout=%d)", fuse->k2, s.Cout);
+    a.in2 = fuse->in2; a.K1 = s.Cout; a.pitch2_shift = sh;
+    a.C = s.Cout + fuse->k2; a.wrow = a.C;
+  }
+  if (fuse && fuse->bias) a.ep_bias = fuse->bias;
   a.Sy = 1; a.Sx = 1; a.OS = s.stride;
   a.OHf = s.H; a.OWf = s.W;
   a.ncls = 0;

@@ -51,6 +51,9 @@ struct SideStream {
   // backward: the downsample branch of a block (BatchNorm-backward apply + dgrad) on a stream of its own, beside conv3 .. conv2
   hipStream_t s2 = nullptr;
   hipEvent_t d_ready = nullptr, d_done = nullptr;      // main: block-output gradient + its partial sums ready / s2: branch gradient written
+  // algebraic BatchNorm backward (backbone.hip): the weight-gradient stream reads the block-output gradient buffer itself
+  hipEvent_t g_ready = nullptr, g_done[2] = {nullptr, nullptr};
+  bool g_done_valid[2] = {false, false};
   int init() {
     if (s) return MMSKIN_OK;
     int least = 0, greatest = 0;
@@ -70,6 +73,9 @@ struct SideStream {
     HIP_CHECK_RET(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
     HIP_CHECK_RET(hipEventCreateWithFlags(&d_ready, hipEventDisableTiming));
     HIP_CHECK_RET(hipEventCreateWithFlags(&d_done, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&g_ready, hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&g_done[0], hipEventDisableTiming));
+    HIP_CHECK_RET(hipEventCreateWithFlags(&g_done[1], hipEventDisableTiming));
     return MMSKIN_OK;
   }
   void destroy() {
@@ -78,6 +84,7 @@ struct SideStream {
     (void)hipEventDestroy(f_ready); (void)hipEventDestroy(f_done); (void)hipEventDestroy(f_staged);
     if (d_ready) (void)hipEventDestroy(d_ready);
     if (d_done) (void)hipEventDestroy(d_done);
+    if (g_ready) { (void)hipEventDestroy(g_ready); (void)hipEventDestroy(g_done[0]); (void)hipEventDestroy(g_done[1]); }
     if (s2) (void)hipStreamDestroy(s2);
     s2 = nullptr;
     (void)hipStreamDestroy(s);

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   const int kb = tile % p.nblk_k; tile /= p.nblk_k;
   const int ob = tile % p.nblk_o;
   const int split = tile / p.nblk_o;
+  const bool ytile = ob >= p.nblk_o_main;                       // Gram tile: the "dY" operand is the input tensor itself
   const int o0 = ob * BO, k0 = kb * BK;
+  const int xcol0 = ytile ? (ob - p.nblk_o_main) * BO : o0;     // first channel of the X rows this tile reads
+  const int xpitch = ytile ? p.Cpitch : p.Cout;
+  const int xcols = ytile ? p.gram_cols : p.Cout;
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
   const int nit = (m_end - m_begin + G * 32 - 1) / (G * 32);
@@ -81,13 +85,16 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
 
   // ---- dY pieces of this wave: piece jx = wid + 8 i -> stage (group) jx / PCX, 1 KB block jx % PCX
   uint32_t x_off[NXW], x_dst[NXW];
-  const uint32_t x_lim = (uint32_t)m_end * (uint32_t)p.Cout * 2u, x_step = (uint32_t)(G * 32) * (uint32_t)p.Cout * 2u;
+  bool x_ok[NXW];
+  const uint32_t x_lim = (uint32_t)m_end * (uint32_t)xpitch * 2u, x_step = (uint32_t)(G * 32) * (uint32_t)xpitch * 2u;
+  const srd_t srdXs = ytile ? srdY : srdX;
 #pragma unroll
   for (int i = 0; i < NXW; ++i) {
     const int jx = wid + 8 * i, gg = jx / PCX, blk = jx - gg * PCX;
     const int L = blk * 64 + lane, r = L / CPRX, c = L - r * CPRX;
     const int sc = c ^ ring_swz<PX>(r);
-    x_off[i] = (uint32_t)((m_begin + gg * 32 + r) * p.Cout + o0 + sc * 8) * 2u;
+    x_off[i] = (uint32_t)((m_begin + gg * 32 + r) * xpitch + xcol0 + sc * 8) * 2u;
+    x_ok[i] = xcol0 + sc * 8 < xcols;
     x_dst[i] = (uint32_t)(gg * STG + blk * 1024);
   }
   // ---- input pieces
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   do {                                                                                                              \
     const uint32_t b_ = lds0 + (bufoff);                                                                            \
     _Pragma("unroll") for (int i = 0; i < NXW; ++i) {                                                               \
-      const uint32_t v_ = x_off[i] < x_lim ? x_off[i] : RING_OOB;                                                   \
-      RING_DMA(v_, srdX, b_ + x_dst[i]);                                                                            \
+      const uint32_t v_ = (x_ok[i] && x_off[i] < x_lim) ? x_off[i] : RING_OOB;                                      \
+      RING_DMA(v_, srdXs, b_ + x_dst[i]);                                                                           \
       x_off[i] += x_step;                                                                                           \
     }                                                                                                               \
     _Pragma("unroll") for (int i = 0; i < NYW; ++i) {                                                               \
@@ -167,6 +174,12 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // Gram tiles: column sums of the X rows through one MFMA per cout fragment against a fragment of ones (waves with wk == 0)
+  f32x4_t acc1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc1[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = ytile && wk == 0 && p.colsum != nullptr;
+  const uint4 ones8 = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
 
   // ---- main loop.  RAW: buffer (it % NIT) was filled by pieces issued NIT - 1 iterations ago; every wave waits for its own
   // (counted vmcnt leaves the NIT - 2 younger iterations in flight), then the barrier makes everybody's visible.  WAR: the
@@ -197,6 +210,11 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fy[i]), __builtin_bit_cast(bf16x8_t, fx[j]),
                                                             acc[i][j], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones8), __builtin_bit_cast(bf16x8_t, fx[j]), acc1[j], 0, 0, 0);
+    }
     buf_rd = buf_rd + ITB == NIT * ITB ? 0 : buf_rd + ITB;
     buf_wr = buf_wr + ITB == NIT * ITB ? 0 : buf_wr + ITB;
   }
@@ -205,6 +223,12 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   ring_wait_vm<0>();
   __syncthreads();
 
+  if (do_colsum && g == 0) {   // every k row of acc1 holds the same sums: row 0 = lanes 0-15, register 0; one partial per (split, group)
+    const int wpad = (p.nblk_o - p.nblk_o_main) * BO;
+    float* cs = p.colsum + (size_t)(split * G + gg) * wpad + xcol0 + wo * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j * 16 + l15] = acc1[j][0];
+  }
   // ---- the G groups hold partial sums of the same tile: groups 1.. park theirs in LDS, group 0 adds
   if constexpr (G > 1) {
     float4* red = reinterpret_cast<float4*>(smem);
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
         }
   }
   // D[i = k index][j = cout]: lane holds cout = l15, k = 4 g + reg -> float4 along k in the slab
-  float* slab = p.slab + (size_t)split * p.Cout * p.Ktot;
+  float* slab = p.slab + (size_t)split * (p.nblk_o * BO) * p.Ktot;   // slab rows = Cout (+ the Gram tiles' rows)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -260,7 +284,91 @@ bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r) {
   r.mps = ceil_div(ceil_div(M, ns), step) * step;
   r.nsplit = ceil_div(M, r.mps);
   r.s1 = false;
+  r.gram_tiles = 0;
   return true;
+}
+
+// ---- dY^T in, in^T in and colsum(in) in one launch (see conv.h)
+bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r) {
+  if (!wgrad_ring_tile(M, Cout, Cin, r)) return false;
+  const int BO = 64 * r.wo, G = 8 / (r.wo * r.wk), step = G * 32;
+  if (Cin % 8 || (uint64_t)M * Cout * 2 >= 0xE0000000ull) return false;
+  r.gram_tiles = ceil_div(Cin, BO);
+  const int tiles = (Cout / BO + r.gram_tiles) * (Cin / (64 * r.wk));
+  static const int target = ring_env("MMSKIN_WGRAD_RING_BLOCKS", 256);
+  int ns = target / tiles > 0 ? target / tiles : 1;
+  const int max_split = M / (step * 8) > 0 ? M / (step * 8) : 1;
+  if (ns > max_split) ns = max_split;
+  r.mps = ceil_div(ceil_div(M, ns), step) * step;
+  r.nsplit = ceil_div(M, r.mps);
+  r.s1 = true;
+  return true;
+}
+static size_t gram_colsum_floats(const WgradRingPlan& r) { return (size_t)r.nsplit * (8 / (r.wo * r.wk)) * r.gram_tiles * 64 * r.wo; }
+size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin) {
+  WgradRingPlan r;
+  if (!wgrad_gram_plan(M, Cout, Cin, r)) return 0;
+  const size_t rows = (size_t)Cout + (size_t)r.gram_tiles * 64 * r.wo;
+  return ((size_t)r.nsplit * rows * Cin + gram_colsum_floats(r)) * sizeof(float);
+}
+
+// sum the split slabs [nsplit][rows][Cin] -> s_out [rows][Cin] and the colsum partials [np][wpad] -> colsum_out [Cin].
+// The output is small (8 - 24 K float4) and the slab count large: 16 float4 columns x 16 slab lanes per block, the lanes meet in LDS
+// (one thread per column walking every slab ran 32 blocks for 95 us).  Deterministic (fixed order).
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restrict__ slab, float4* __restrict__ s_out, int nsplit, int total4,
+                                                          const float* __restrict__ cpart, float* __restrict__ colsum_out, int np, int wpad, int Cin) {
+  __shared__ float4 red[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + cx;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total4)
+    for (int k = ry; k < nsplit; k += 16) { const float4 u = slab[(size_t)k * total4 + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+  red[ry][cx] = a;
+  __syncthreads();
+  if (ry == 0 && i < total4) {
+    float4 t = red[0][cx];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) { const float4 u = red[j][cx]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    s_out[i] = t;
+  }
+  if (blockIdx.x == gridDim.x - 1) {   // column sums: Cin in {64, 128, 256} columns x (256 / Cin) row lanes over the np partial rows
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(red);
+    const int col = threadIdx.x % Cin, ln = threadIdx.x / Cin, nl = 256 / Cin;
+    float s0 = 0.f, s1 = 0.f;
+    int k = ln;
+    for (; k + nl < np; k += 2 * nl) { s0 += cpart[(size_t)k * wpad + col]; s1 += cpart[(size_t)(k + nl) * wpad + col]; }
+    if (k < np) s0 += cpart[(size_t)k * wpad + col];
+    redf[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (ln == 0) {
+      float s = redf[col];
+      for (int j = 1; j < nl; ++j) s += redf[j * Cin + col];
+      colsum_out[col] = s;
+    }
+  }
+}
+
+int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, const bf16_t* in, float* slab, float* s_out, float* colsum_out,
+                      hipStream_t st) {
+  WgradRingPlan r;
+  const int M = N * H * W;
+  ARG_CHECK(wgrad_gram_plan(M, Cout, Cin, r) && (Cin == 64 || Cin == 128 || Cin == 256), "wgrad_gram: shape Cout=%d Cin=%d not tiled by the ring kernel", Cout, Cin);
+  WgradArgs a = {};
+  a.dy = g; a.in = in; a.slab = slab;
+  a.N = N; a.IH = H; a.IW = W; a.C = Cin; a.Cpitch = Cin; a.OH = H; a.OW = W;
+  a.Cout = Cout; a.Ktot = Cin; a.Sy = 1; a.Sx = 1; a.ntaps = 1; a.M = M; a.simple1x1 = 1;
+  const size_t rows = (size_t)Cout + (size_t)r.gram_tiles * 64 * r.wo;
+  a.gram_cols = Cin;
+  a.colsum = slab + (size_t)r.nsplit * rows * Cin;
+  int rc = wgrad_ring_launch(a, r, st);
+  if (rc) return rc;
+  const int total4 = (int)(rows * Cin / 4);
+  const int G = 8 / (r.wo * r.wk);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ceil_div(total4, 16)), dim3(256), 0, st, reinterpret_cast<const float4*>(slab),
+                     reinterpret_cast<float4*>(s_out), r.nsplit, total4, a.colsum, colsum_out, r.nsplit * G, r.gram_tiles * 64 * r.wo, Cin);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
 }
 
 bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r) {
@@ -303,7 +411,9 @@ extern "C" int64_t mmskin_wgrad_ring_launches(void) { return g_ring_launches; }
 
 int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st) {
   a.nsplit = r.nsplit; a.m_per_split = r.mps;
-  a.nblk_o = a.Cout / (64 * r.wo); a.nblk_k = a.Ktot / (64 * r.wk);
+  a.nblk_o_main = a.Cout / (64 * r.wo);
+  a.nblk_o = a.nblk_o_main + r.gram_tiles; a.nblk_k = a.Ktot / (64 * r.wk);
+  if (!r.gram_tiles) { a.gram_cols = 0; a.colsum = nullptr; }
   ++g_ring_launches;
   // ring depth: G = 1 tiles move 24 KB per iteration (4 deep = 96 KB), G = 2 tiles 32 - 40 KB (3 deep = 96 - 120 KB)
   static const int deep = ring_env("MMSKIN_WGRAD_RING_DEEP", 1);
