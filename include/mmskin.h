@@ -121,6 +121,7 @@ double mmskin_conv2d_wgrad_time(int N, int Cin, int H, int W, int Cout, int kh, 
 int64_t mmskin_conv_pipe_launches(void);
 /* launches of the ring weight-gradient kernel (wgrad_ring.hip) since load: tests assert the path they mean to cover ran */
 int64_t mmskin_wgrad_ring_launches(void);
+int64_t mmskin_wgrad3_ring_launches(void);   /* ... of the all-taps 3x3 ring kernel (wgrad3_ring.hip) */
 /* Algebraic BatchNorm backward of an expanding 1x1 convolution x = conv(y, w) (csrc/abn.hip; bf16 operands): with
  * dz = cA g + cB x + cC per channel, dy = dz w and dw = dz^T y are computed from g, y, w and the coefficients alone
  * (dy = [g | y][cA w ; w^T diag(cB) w] + cC w, dw = cA (g^T y) + cB (w (y^T y)) + cC (x) colsum(y)): neither dz nor x is read.

@@ -197,6 +197,10 @@ template <typename T>
 int launch_stem_conv_wgrad(int N, int OH, int OW, int Hp, int Wp, const T* dout, const T* img4,
                            float* slab, float* dwv, hipStream_t st);
 
+// all-taps 3x3 / stride 1 / pad 1 weight gradient, ring form (wgrad3_ring.hip): launches the GEMM; the caller reduces *nsplit slabs [Cout][9 Cin]
+bool wgrad3_ring_takes(const ConvShape& s, int* nsplit);
+int launch_wgrad3_ring(const ConvShape& s, const bf16_t* dout, const bf16_t* in, float* slab, hipStream_t st, int* nsplit);
+
 // algebraic BatchNorm backward of an expanding 1x1 convolution (abn.hip)
 int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, int C4, int Cw, bf16_t* wd, float* bias, float* coef_copy,
              hipStream_t st);

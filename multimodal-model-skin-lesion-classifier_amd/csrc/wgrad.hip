@@ -694,8 +694,10 @@ static bool wgrad3_plan(const ConvShape& s, Wgrad3Args& a) {
 }
 static size_t wgrad3_slab_bytes(const ConvShape& s) {
   Wgrad3Args a = {};
-  if (!wgrad3_plan(s, a)) return 0;
-  return (size_t)(a.nsplit + (a.nsplit > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * s.Cout * 9 * s.Cin * sizeof(float);
+  int ns = wgrad3_plan(s, a) ? a.nsplit : 0, nr = 0;
+  if (wgrad3_ring_takes(s, &nr) && nr > ns) ns = nr;
+  if (!ns) return 0;
+  return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * s.Cout * 9 * s.Cin * sizeof(float);
 }
 static int launch_wgrad3(const ConvShape& s, Wgrad3Args& a, const bf16_t* dout, const bf16_t* in, float* slab, float* dw,
                          hipStream_t st, int cout_valid, int cin_valid) {
@@ -716,6 +718,12 @@ int launch_conv_wgrad(const ConvShape& s, const T* dout, const T* in, float* sla
                       hipStream_t st, int cout_valid, int cin_valid) {
   ARG_CHECK(s.kh * s.kw <= MMSKIN_MAX_TAPS, "wgrad: too many taps");
   if constexpr (sizeof(T) == 2) {
+    int nsr = 0;
+    if (wgrad3_ring_takes(s, &nsr)) {
+      int rc = launch_wgrad3_ring(s, dout, in, slab, st, &nsr);
+      if (rc) return rc;
+      return reduce_slabs(slab, nsr, s.Cout, 9 * s.Cin, dw_oihw, s.Cin, 9, cout_valid, cin_valid, st);
+    }
     Wgrad3Args a3 = {};
     if (wgrad3_plan(s, a3)) return launch_wgrad3(s, a3, dout, in, slab, dw_oihw, st, cout_valid, cin_valid);
   }

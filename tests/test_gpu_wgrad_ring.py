@@ -70,6 +70,40 @@ def test_ring_wgrad_matches_fp64_reference(case):
     assert err < TOL, (what, err)
 
 
+CASES3 = [
+    # N, Cin, H, W, Cout, what  (3x3 / stride 1 / pad 1: csrc/wgrad3_ring.hip)
+    (3, 64, 56, 56, 64, "one 56-wide row per stage, 64-cout tile: two groups take alternate stages and meet in LDS"),
+    (5, 64, 14, 14, 128, "four rows per stage, ragged last stage of every image (14 = 4+4+4+2), 128-cout tile"),
+    (3, 128, 28, 28, 128, "two rows per stage, two cin tiles"),
+    (4, 128, 7, 7, 256, "whole 7x7 images per stage, two cout tiles x two cin tiles"),
+    (2, 64, 9, 13, 64, "odd sizes: 4 rows of 13"),
+    (6, 64, 28, 28, 64, "64-cout tile at width 28"),
+    (9, 64, 7, 7, 64, "64-cout tile at width 7: odd stage count, the second group's last stage is empty"),
+    (70, 64, 14, 14, 64, "16 splits that start inside images"),
+    (40, 128, 14, 14, 128, "128-cout tile over 10 splits"),
+]
+
+
+@pytest.mark.parametrize("case", CASES3, ids=[f"k{i}" for i in range(len(CASES3))])
+def test_ring_wgrad3x3_matches_fp64_reference(case):
+    N, Cin, H, W, Cout, what = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = _bf16_exact(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    dy = _bf16_exact(torch.randn(N, Cout, H, W, generator=g))
+    wr = w.double().requires_grad_(True)
+    F.conv2d(x.double(), wr, stride=1, padding=1).backward(dy.double())
+    n0 = lib.mmskin_wgrad3_ring_launches()
+    _, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert lib.mmskin_wgrad3_ring_launches() == n0 + 1, "3x3 ring kernel not selected"
+    err = rel_err(dw, wr.grad)
+    # every tap separately: a wrong window row / column offset shows in one tap plane only
+    per_tap = [rel_err(dw[:, :, t // 3, t % 3], wr.grad[:, :, t // 3, t % 3]) for t in range(9)]
+    _record(test="wgrad3_ring", case=list(case[:5]), what=what, max_err_over_rms=err, worst_tap=max(per_tap))
+    assert err < TOL and max(per_tap) < TOL, (what, err, per_tap)
+
+
 def test_ring_wgrad_is_bit_identical_across_repeats():
     """A race in the ring (a fragment read overtaking its DMA, a refill overtaking a read, the group reduction overtaking the drain of
     the trailing pieces) shows as run-to-run differences: 100 launches of a multi-split two-group layer must give one result."""
@@ -84,3 +118,13 @@ def test_ring_wgrad_is_bit_identical_across_repeats():
     for i in range(100):
         _, dw = conv_backward(dy, x, w, 1, 0, "bf16")
         assert torch.equal(dw, ref), i
+    # and the 3x3 ring (two groups, ring of two iterations: the tightest WAR distance)
+    x3 = _bf16_exact(torch.randn(32, 64, 28, 28, generator=g)).to(DEV)
+    dy3 = _bf16_exact(torch.randn(32, 64, 28, 28, generator=g)).to(DEV)
+    w3 = torch.zeros(64, 64, 3, 3, device=DEV)
+    n0 = lib.mmskin_wgrad3_ring_launches()
+    _, ref3 = conv_backward(dy3, x3, w3, 1, 1, "bf16")
+    assert lib.mmskin_wgrad3_ring_launches() == n0 + 1
+    for i in range(100):
+        _, dw = conv_backward(dy3, x3, w3, 1, 1, "bf16")
+        assert torch.equal(dw, ref3), i
