@@ -433,11 +433,29 @@ def main():
                 traffic_note = f"committed PMC pass is for sources {tj.get('source_hash')}, this build is {source_hash()}"
         except OSError:
             pass
+        # whole-step HBM bytes (every kernel, PMC) of exactly these sources: profiles/step_traffic.json, else null
+        step_bytes = step_gbps = wgrad_prod_ms = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "step_traffic.json")) as f:
+                sj = json.load(f)
+            if sj.get("source_hash") == source_hash():
+                step_bytes = sj.get("step_bytes")
+                step_gbps = round(step_bytes / (dt / args.steps) / 1e9, 1)
+        except OSError:
+            pass
+        if prod_us:
+            wgrad_prod_ms = (tj.get("production_trace") or {}).get("wgrad_gemm_ms_per_step")
+        classes["wgrad"]["production_ms_per_step"] = wgrad_prod_ms
+        # frac = the PRODUCTION figure (the dominant kernel's launches as they run in the timed step, beside the weight-gradient stream:
+        # committed un-instrumented trace of exactly these sources) when one is committed, else the live isolated one (side stream off)
+        frac_live = round(achieved / peak, 4)
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    # frac = frac_isolated: this pass runs with the side stream off; frac_production: the same launches beside the
-                    # weight-gradient stream (committed trace of these sources, null when the sources differ)
-                    "frac_isolated": round(achieved / peak, 4), "frac_production": frac_production,
+                    "achieved": round(achieved if frac_production is None else frac_production * peak, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": frac_live if frac_production is None else frac_production,
+                    "frac_basis": "isolated (live HIP events, side stream off)" if frac_production is None else "production (committed kernel trace of these sources)",
+                    "achieved_isolated": round(achieved, 2),
+                    "frac_isolated": frac_live, "frac_production": frac_production,
+                    "step_bytes": step_bytes, "step_gbps": step_gbps,
                     "production_avg_launch_us": prod_us, "mfma_busy_share": mfma_busy,
                     "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n_launch),
                     "algorithmic_gbytes_per_launch": round(dom_by / max(n_launch, 1) / 1e9, 4),

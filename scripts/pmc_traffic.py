@@ -69,6 +69,11 @@ if len(sys.argv) > 5:   # production launch time of the same kernel: un-instrume
     cg = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if dom(r["Kernel_Name"])]
     out["production_trace"] = {"source": "rocprofv3 --kernel-trace --stats, python3 bench.py --steps 10 --warmup 1 (side stream on), last 60 % of the dispatches",
                                "conv_gemm_launches": len(cg), "conv_gemm_total_ms": sum(cg) / 1e6, "avg_launch_us": sum(cg) / len(cg) / 1e3}
+    # the weight-gradient GEMMs (side stream) of the same trace, per step: conv launches per step = launches_per_step of the PMC pass
+    wg = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"]]
+    steps = len(cg) / float(n1)
+    out["production_trace"]["wgrad_gemm_ms_per_step"] = sum(wg) / 1e6 / steps
+    out["production_trace"]["steps_in_window"] = steps
 with open(sys.argv[3], "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps(out, indent=1))

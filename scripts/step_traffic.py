@@ -14,7 +14,7 @@ def load(directory, counter):
 
 
 def klass(n):
-    for key, name in (("wgrad", "weight gradient (+ slab reduction)"), ("conv_gemm_kernel", "conv forward + dgrad"), ("conv3x3_c64", "conv forward + dgrad"),
+    for key, name in (("wgrad", "weight gradient (+ slab reduction)"), ("gram_reduce", "weight gradient (+ slab reduction)"), ("abn_", "algebraic BatchNorm backward (fold / fix-up)"), ("conv_gemm_kernel", "conv forward + dgrad"), ("conv3x3_c64", "conv forward + dgrad"),
                       ("bn_bwd_apply", "BatchNorm backward apply"), ("bn_apply", "BatchNorm forward apply"), ("stem_", "stem (pack / pool / BatchNorm)"),
                       ("bn_", "BatchNorm reductions / finalize"), ("partial_reduce", "BatchNorm reductions / finalize"), ("stage_weights", "weight staging"),
                       ("multi_tensor_apply", "Adam"), ("avgpool", "pooling"), ("parity_zero_fill", "conv forward + dgrad")):
@@ -52,4 +52,12 @@ lines = [f"HBM traffic of one {TITLE or 'ResNet-50 + crossattention'} training s
 for k, a in sorted(agg.items(), key=lambda kv: -(kv[1][0] + kv[1][1]))[:28]:
     lines.append(f"{k:72s} {a[2]:8d} {a[0] / 1e9:9.2f} {a[1] / 1e9:9.2f} {100 * (a[0] + a[1]) / (tot_r + tot_w):6.1f}%")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
+if len(sys.argv) > 5:   # machine-readable totals for bench.py (keyed by the kernel sources they were measured on)
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_hash
+    json.dump({"source_hash": source_hash(), "step_read_bytes": tot_r, "step_write_bytes": tot_w, "step_bytes": tot_r + tot_w,
+               "by_class": {k: {"launches": a[2], "read_bytes": a[0], "write_bytes": a[1]} for k, a in agg.items()},
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, every kernel of the timed step), FETCH_SIZE doubled (gfx950)"},
+              open(sys.argv[5], "w"), indent=1)
 print("\n".join(lines))

@@ -6,7 +6,11 @@ launch to it and MMSKIN_CONV_PIPE_TILE pins the tile height (256 / 224 computed 
 shape meets every case: ragged last row blocks, M smaller than one tile, stride-2 gathers, the four parity classes of a stride-2 dgrad,
 a one-K-tile reduction (prologue-only pipeline) and 72 K-tiles.  Both knobs are read once per process -> fresh interpreters.
 Reference semantics: F.conv2d forward / backward as reached through torchvision's ResNet (loadImageModelClassifier.py:65-75).
-Tolerance: the bf16 kernel bound of test_gpu_kernels.py (5e-2 of the output rms)."""
+Tolerance (round 4): inputs, weights and upstream gradients are bf16-REPRESENTABLE and the reference runs in fp64,
+so the only error left is the bf16 rounding of the stored result: EVERY element within half a bf16 ulp (2^-8 relative) of the exact value,
+and against the reference ROUNDED to bf16 the relative L2 is < 1e-3 (only rounding ties may differ) -- one dropped 8-element fragment of a
+K = 4608 reduction moves an element by ~4e-2 of the rms and fails both.  Measured errors go to
+gpurun_out/parity_report.jsonl."""
 import os
 import subprocess
 import sys
@@ -18,10 +22,15 @@ pytestmark = pytest.mark.gpu
 CODE = r'''
 import sys
 sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
-import torch, torch.nn.functional as F
+import json, os, torch, torch.nn.functional as F
 from gpu_util import DEV, conv_backward, conv_forward, rel_err
 from mmskin import _lib
 lib = _lib.load()
+REPORT = os.path.join(%(root)r, "gpurun_out", "parity_report.jsonl")
+def rb(t): return t.bfloat16().float()
+def l2r(got, want):
+    got, want = got.double().cpu(), rb(want.float()).double()
+    return float((got - want).norm() / want.norm())
 CASES = [  # N, Cin, H, W, Cout, k, stride, pad, pipe launches expected (forward, dgrad)
     (3, 256, 14, 14, 256, 3, 1, 1, 1, 1),     # layer3 3x3: 588 rows = 3 images of 196
     (2, 256, 28, 28, 256, 3, 2, 1, 1, 1),     # stride-2 3x3: strided gather forward, four parity classes backward
@@ -35,21 +44,29 @@ CASES = [  # N, Cin, H, W, Cout, k, stride, pad, pipe launches expected (forward
 ]
 g = torch.Generator().manual_seed(5)
 for (N, Cin, H, W, Cout, k, s, p, ef, eb) in CASES:
-    x = torch.randn(N, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
-    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, stride=s, padding=p)
-    dy = torch.randn(y_ref.shape, generator=g)
-    y_ref.backward(dy)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy.double())
     n0 = lib.mmskin_conv_pipe_launches()
     y = conv_forward(x.to(DEV), w.to(DEV), s, p, "bf16")
     n1 = lib.mmskin_conv_pipe_launches()
     dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), s, p, "bf16")
     n2 = lib.mmskin_conv_pipe_launches()
     ef_, eb_ = rel_err(y, y_ref), rel_err(dx, xr.grad)
-    print("CASE", (N, Cin, H, W, Cout, k, s, p), "fwd", ef_, "dgrad", eb_, "pipe launches", n1 - n0, n2 - n1, flush=True)
+    lf_, lb_ = l2r(y, y_ref.detach()), l2r(dx, xr.grad)
+    print("CASE", (N, Cin, H, W, Cout, k, s, p), "fwd", ef_, lf_, "dgrad", eb_, lb_, "pipe launches", n1 - n0, n2 - n1, flush=True)
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(dict(test="conv_pipe", tile=os.environ.get("MMSKIN_CONV_PIPE_TILE"), case=[N, Cin, H, W, Cout, k, s, p], fwd_max_err_over_rms=ef_,
+                                fwd_rel_l2_vs_bf16_rounded_ref=lf_, dgrad_max_err_over_rms=eb_, dgrad_rel_l2_vs_bf16_rounded_ref=lb_)) + "\n")
     assert n1 - n0 == ef and n2 - n1 == eb, "pipelined kernel not selected as expected"
-    assert ef_ < 5e-2 and eb_ < 5e-2
+    for got, want in ((y, y_ref.detach()), (dx, xr.grad)):   # every stored element within half a bf16 ulp (2^-8 relative) of the exact value
+        got, want = got.double().cpu(), want.double()
+        assert bool(((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-5 * float(want.pow(2).mean().sqrt())).all()), (ef_, eb_)
+    assert lf_ < 1e-3 and lb_ < 1e-3, (lf_, lb_)
 '''
 
 

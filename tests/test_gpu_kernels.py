@@ -54,6 +54,40 @@ def test_conv_forward_backward(case, dtype):
     assert rel_err(dw, wr.grad) < TOL[dtype], ("wgrad", rel_err(dw, wr.grad))
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bf16_tight_on_representable_inputs(case):
+    """The bf16 kernels on bf16-REPRESENTABLE inputs against an fp64 reference: the operands are exact, so what is
+    left is the rounding of the stored result (forward / dgrad: EVERY element within half a bf16 ulp of the exact value, relative L2 against the reference
+    rounded to bf16 < 1e-3) and the fp32 summation order (wgrad, fp32 output: < 1e-4).  A dropped 8-element fragment fails all three."""
+    import json
+    N, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    rb = lambda t: t.bfloat16().float()
+    x = rb(torch.randn(N, Cin, H, W, generator=g))
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = rb(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(dy.double())
+    y = conv_forward(x.to(DEV), w.to(DEV), stride, pad, "bf16")
+    dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), stride, pad, "bf16")
+    def l2r(got, want):
+        got, want = got.double().cpu(), rb(want.float()).double()
+        return float((got - want).norm() / (want.norm() + 1e-30))
+    rec = dict(test="conv_bf16_tight", case=list(case), fwd=rel_err(y, y_ref), fwd_l2r=l2r(y, y_ref.detach()), dgrad=rel_err(dx, xr.grad),
+               dgrad_l2r=l2r(dx, xr.grad), wgrad=rel_err(dw, wr.grad))
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
+    os.makedirs(os.path.dirname(rep), exist_ok=True)
+    with open(rep, "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    # every stored element within half a bf16 ulp (2^-8 relative) of the exact value, plus the fp32 summation noise
+    for got, want in ((y, y_ref.detach()), (dx, xr.grad)):
+        got, want = got.double().cpu(), want.double()
+        assert bool(((got - want).abs() <= want.abs() * 2.0 ** -8 + 1e-5 * float(want.pow(2).mean().sqrt())).all()), rec
+    assert rec["fwd_l2r"] < 1e-3 and rec["dgrad_l2r"] < 1e-3, rec
+    assert rec["wgrad"] < 1e-4, rec
+
+
 def test_conv_rejects_unsupported_shapes():
     x = torch.zeros(1, 3, 8, 8, device=DEV)
     w = torch.zeros(16, 3, 3, 3, device=DEV)

@@ -11,6 +11,7 @@ import pytest
 import torch
 import torch.nn as nn
 
+import step_fixtures as sf
 from helpers import (CLASS_WEIGHTS, SMALL, check_record_against_golden, disable_dropout, golden,
                      train_step_record)
 from gpu_util import DEV, rel_err
@@ -143,6 +144,40 @@ def stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip):
     return rec
 
 
+def stage_report_rec(rc, rh):
+    """stage_report on step RECORDS (tests/step_fixtures.py): `rc` the CPU side recorded in the build container
+    (tests/golden/step_*.npz), `rh` the record of the HIP step -- gradients at the same seeded sample of coordinates."""
+    rec = {"err_train_logits": float((rc["out"] - rh["out"]).abs().max()), "loss_cpu": rc["loss"], "loss_hip": rh["loss"]}
+    rec["running_mean_rel_max"] = max(rel_err(rh["stats"][n][0], rc["stats"][n][0]) for n in rc["stats"])
+    rec["running_var_rel_max"] = max(rel_err(rh["stats"][n][1], rc["stats"][n][1]) for n in rc["stats"])
+    if rc["grads"]:
+        head = [k for k in rc["grads"] if not k.startswith("image_encoder")]
+        rec["head_grad_l2_max"] = max(sf.l2(rh["grads"][k], rc["grads"][k]) for k in head)
+        rec["head_grad_cos_min"] = min(sf.cos(rh["grads"][k], rc["grads"][k]) for k in head if float(rc["grads"][k].abs().max()) > 0)
+        for st in STAGES:
+            names = st.split("|")
+            keys = [k for k in rc["grads"] if any(k.startswith("image_encoder." + n) for n in names)]
+            rec["cos_" + names[0]], rec["l2_" + names[0]] = sf.stage_stats(rh, rc, keys)
+    return rec
+
+
+def hip_step_record(hip, img, meta, lab, backward=True):
+    if backward:
+        out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
+        return sf.record(hip, out_h, loss_h, g_h)
+    out_h, loss_h = _train_forward(hip, img, meta, lab, DEV)
+    return sf.record(hip, out_h, loss_h)
+
+
+def build_hip(dtype="fp32", gamma=None, **kw):
+    """the HIP model at the deterministic init of the fixtures (the CPU oracle is only constructed for its state_dict)"""
+    cpu, hip = build_pair(dtype, **kw)
+    if gamma is not None:
+        damp_residual_branches(hip, gamma)
+    del cpu
+    return hip
+
+
 @pytest.mark.parametrize("arch,dtype", [("resnet-18", "fp32"), ("resnet-50", "fp32"), ("resnet-50", "bf16")])
 def test_resnet_end_to_end_vs_oracle(arch, dtype):
     """Backbone + crossattention head: eval logits and a full train step against the CPU oracle.
@@ -228,7 +263,9 @@ RESNET50_KW = dict(SMALL, cnn_model_name="resnet-50", common_dim=512, text_encod
 def test_bf16_train_step_parity_at_baseline_shape():
     """THE benchmarked path (BASELINE configs[1]): ONE train step (dropout off, BatchNorm batch statistics; the step of
     train_pad_20.py:102-113) of ResNet-50 + crossattention at B = 256 @ 224^2 with bf16 backbone compute, HIP vs the fp32
-    CPU oracle.  Two parameter points:
+    CPU oracle.  The oracle / emulation sides come from tests/golden/step_b256_*.npz (recorded in the build container by
+    tests/golden/gen_step_golden.py: three CPU steps at this size were 170 - 185 s of the GPU box's clock); gradients are
+    compared at the fixtures' seeded coordinate samples (tests/step_fixtures.py).  Two parameter points:
 
     (a) conditioned: the last BatchNorm of every residual block has gamma 0.25 -- residual branches small against the skip
         path, as in a trained network.  Here the north_star bound means something and is asserted as stated: train-mode
@@ -236,36 +273,40 @@ def test_bf16_train_step_parity_at_baseline_shape():
         relative L2 of the backbone gradients (thresholds = 3-5x the values measured on MI355X, gpurun_out/parity_report.jsonl).
     (b) torchvision's default init (gamma 1): sixteen full-strength random branches make the train-mode network chaotic --
         no bf16 execution is within 1e-2 (see test_resnet_end_to_end_vs_oracle); the HIP step must be no further from
-        the fp32 oracle than the CPU bf16-storage emulation of the same step (x1.25)."""
+        the fp32 oracle than the CPU bf16-storage emulation of the same step (x1.25), and -- the assertion with power on the
+        early layers, where both are decorrelated from fp32 -- its gradient must agree with the EMULATION's: both round the
+        same operands.  Measured: they do NOT agree to 0.9 -- cosine(HIP, emulation) is 0.32 - 0.36 on layers 1 - 3 and 0.58 on layer 4
+        (against 0.15 - 0.40 for either one versus fp32): at this parameter point any two bf16 executions decorrelate from each other,
+        so the assertion with power stays the conditioned point (a) and the kernel tests; the cosine is recorded and floored."""
     img, meta, lab = _baseline_batch(256)
     # ---- (a)
-    cpu, hip = build_pair("bf16", **RESNET50_KW)
-    damp_residual_branches(cpu, 0.25); damp_residual_branches(hip, 0.25)
-    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
-    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
-    r = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    rc = sf.load("step_b256_g025")
+    hip = build_hip("bf16", 0.25, **RESNET50_KW)
+    rh = hip_step_record(hip, img, meta, lab)
+    r = stage_report_rec(rc, rh)
     report(test="bf16_b256_conditioned", **r)
-    assert set(g_c) == set(g_h) and all(torch.isfinite(v).all() for v in g_h.values())
+    assert set(rc["grads"]) == set(rh["grads"]) and all(torch.isfinite(v).all() for v in rh["grads"].values())
     assert r["err_train_logits"] < 1e-2, r                                           # north_star: 1e-2 bf16 (measured 1.4e-3)
-    assert abs(loss_c - loss_h) < 5e-4, r                                            # measured 4e-5
+    assert abs(r["loss_cpu"] - r["loss_hip"]) < 5e-4, r                              # measured 4e-5
     assert r["running_mean_rel_max"] < 2e-2 and r["running_var_rel_max"] < 1e-3, r   # measured 3.9e-3 / 6e-5
     assert r["head_grad_l2_max"] < 0.1 and r["head_grad_cos_min"] > 0.995, r         # measured 2.9e-2 / 0.9996
     floors = {"cos_conv1": 0.80, "cos_layer1": 0.80, "cos_layer2": 0.82, "cos_layer3": 0.85, "cos_layer4": 0.92}
     for k, v in floors.items():                                                     # measured 0.876 / 0.884 / 0.892 / 0.914 / 0.964
         assert r[k] > v, (k, r[k])                                                   # (the CPU bf16 emulation: the same to 3e-3)
     assert r["l2_layer4"] < 0.4 and r["l2_conv1"] < 0.65, r                          # measured 0.27 / 0.50
-    del cpu, hip, g_c, g_h
+    del hip
     # ---- (b)
-    cpu, hip = build_pair("bf16", **RESNET50_KW)
-    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
-    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
-    r_hip = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
-    del hip, g_h
-    emu = bf16_storage_emulation(det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu"))))
-    out_e, loss_e, g_e = _step(emu, _rb(img), meta, lab, "cpu")
-    r_emu = stage_report(out_c, loss_c, g_c, out_e, loss_e, g_e, cpu, emu)
-    report(test="bf16_b256_default_init", hip=r_hip, emu=r_emu)
+    rc, re = sf.load("step_b256_default"), sf.load("step_b256_default_emu")
+    hip = build_hip("bf16", None, **RESNET50_KW)
+    rh = hip_step_record(hip, img, meta, lab)
+    r_hip, r_emu = stage_report_rec(rc, rh), stage_report_rec(rc, re)
+    vs_emu = stage_report_rec(re, rh)     # HIP against the emulation itself
+    report(test="bf16_b256_default_init", hip=r_hip, emu=r_emu, hip_vs_emulation={k: v for k, v in vs_emu.items() if k.startswith(("cos_", "l2_"))})
     assert_not_worse_than_emulation(r_hip, r_emu, slack=1.25)
+    assert vs_emu["cos_layer4"] >= VS_EMU_COS_FLOOR, vs_emu
+
+
+VS_EMU_COS_FLOOR = 0.45   # cosine(HIP gradient, emulation gradient) of layer4 at the default init: measured 0.58 (layers 1-3: 0.32 - 0.36) -- two bf16 executions of this chaotic parameter point decorrelate from EACH OTHER, not only from fp32 (parity report: hip_vs_emulation)
 
 
 def _train_forward(model, img, meta, lab, dev):
@@ -293,23 +334,16 @@ def test_bf16_train_logit_error_over_last_bn_gamma(gamma):
     bound on the TRAIN-mode logits break?  The benchmarked configuration at B = 256 @ 224^2 with the last BatchNorm of every
     residual block at gamma in {0.1, 0.5, 0.75} (0.25 and 1.0, with the whole backward, are
     test_bf16_train_step_parity_at_baseline_shape); for each point the train-mode FORWARD (batch statistics, running statistics
-    updated) of the HIP model, the fp32 CPU oracle and the CPU bf16-storage emulation go to parity_report.jsonl -- forward only:
-    three full CPU steps at B = 256 per point made this test a third of the GPU suite's wall time.  Asserted at EVERY point: the
-    HIP logits / loss / running statistics are no further from the fp32 oracle than 1.25 x the emulation's, and the logits meet
-    the north_star's 1e-2 wherever the emulation does.  Reference semantics: the forward of one
-    optimisation step of train_pad_20.py:102-113."""
+    updated) of the HIP model is compared with the fp32 CPU oracle's and the CPU bf16-storage emulation's, both recorded in the
+    build container (tests/golden/step_b256_fwd_g*.npz).  Asserted at EVERY point: the HIP logits / loss / running statistics are no
+    further from the fp32 oracle than 1.25 x the emulation's, and the logits meet the north_star's 1e-2 wherever the emulation does
+    (VERDICT r02 item 6a).  Reference semantics: the forward of one optimisation step of train_pad_20.py:102-113."""
     img, meta, lab = _baseline_batch(256)
-    cpu, hip = build_pair("bf16", **RESNET50_KW)
-    damp_residual_branches(cpu, gamma); damp_residual_branches(hip, gamma)
-    out_c, loss_c = _train_forward(cpu, img, meta, lab, "cpu")
-    out_h, loss_h = _train_forward(hip, img, meta, lab, DEV)
-    r_hip = _forward_report(out_c, loss_c, out_h, loss_h, cpu, hip)
-    del hip
-    emu = det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu")))
-    damp_residual_branches(emu, gamma)
-    emu = bf16_storage_emulation(emu)
-    out_e, loss_e = _train_forward(emu, _rb(img), meta, lab, "cpu")
-    r_emu = _forward_report(out_c, loss_c, out_e, loss_e, cpu, emu)
+    tag = str(gamma).replace(".", "")
+    rc, re = sf.load(f"step_b256_fwd_g{tag}"), sf.load(f"step_b256_fwd_g{tag}_emu")
+    hip = build_hip("bf16", gamma, **RESNET50_KW)
+    rh = hip_step_record(hip, img, meta, lab, backward=False)
+    r_hip, r_emu = stage_report_rec(rc, rh), stage_report_rec(rc, re)
     report(test="bf16_b256_gamma_sweep", gamma=gamma, hip=r_hip, emu=r_emu)
     for k in ("err_train_logits", "running_mean_rel_max", "running_var_rel_max"):
         assert r_hip[k] <= 1.25 * r_emu[k] + 1e-4, (k, r_hip[k], r_emu[k])
@@ -323,25 +357,21 @@ def test_fp32_train_step_parity_at_production_size():
     launches of > 640 / 800 workgroups, the two-stage slab reduction for > 32 splits, the wgrad split policy, the parity
     zero fill with large 3-D grids) with a QUANTITATIVE backward check: loss, logits and the encoder gradients
     -- per stage, plus the stem conv, a layer1 conv3, the layer2 downsample conv and a layer4 BatchNorm -- under the
-    noise-aware rule of test_resnet_end_to_end_vs_oracle (truth = the oracle in fp64; HIP fp32 at most 3x as far as CPU fp32)."""
+    noise-aware rule of test_resnet_end_to_end_vs_oracle (truth = the oracle in fp64; HIP fp32 at most 3x as far as CPU fp32).
+    The CPU fp32 and fp64 steps are recorded fixtures (tests/golden/step_b64_fp32.npz / step_b64_fp64.npz)."""
     img, meta, lab = _baseline_batch(64)
-    cpu, hip = build_pair("fp32", **RESNET50_KW)
-    truth = det_init_(OracleMultimodalModel(**dict(RESNET50_KW, device="cpu"))).double()
-    out_c, loss_c, g_c = _step(cpu, img, meta, lab, "cpu")
-    out_h, loss_h, g_h = _step(hip, img, meta, lab, DEV)
-    truth.train(); disable_dropout(truth)
-    out_t = truth(img.double(), meta.double())
-    nn.CrossEntropyLoss(weight=torch.tensor(CLASS_WEIGHTS, dtype=torch.float64))(out_t, lab).backward()
-    g_t = {k: p.grad for k, p in truth.named_parameters() if p.grad is not None}
-    r = stage_report(out_c, loss_c, g_c, out_h, loss_h, g_h, cpu, hip)
+    rc, rt = sf.load("step_b64_fp32"), sf.load("step_b64_fp64")
+    hip = build_hip("fp32", None, **RESNET50_KW)
+    rh = hip_step_record(hip, img, meta, lab)
+    r = stage_report_rec(rc, rh)
     picks = ["image_encoder.conv1.weight", "image_encoder.layer1.1.conv3.weight", "image_encoder.layer2.0.downsample.0.weight",
              "image_encoder.layer4.2.bn3.weight", "image_encoder.layer4.2.bn3.bias"]
-    dist = {k: (_l2(g_h[k], g_t[k]), _l2(g_c[k], g_t[k])) for k in picks}
-    keys = [k for k in g_t if k.startswith("image_encoder")]
-    hip_l2 = sorted(_l2(g_h[k], g_t[k]) for k in keys); cpu_l2 = sorted(_l2(g_c[k], g_t[k]) for k in keys)
+    dist = {k: (sf.l2(rh["grads"][k], rt["grads"][k]), sf.l2(rc["grads"][k], rt["grads"][k])) for k in picks}
+    keys = [k for k in rt["grads"] if k.startswith("image_encoder")]
+    hip_l2 = sorted(sf.l2(rh["grads"][k], rt["grads"][k]) for k in keys); cpu_l2 = sorted(sf.l2(rc["grads"][k], rt["grads"][k]) for k in keys)
     report(test="fp32_b64_224", picks=dist, hip_l2_median=hip_l2[len(keys) // 2], cpu_l2_median=cpu_l2[len(keys) // 2],
            hip_l2_max=hip_l2[-1], cpu_l2_max=cpu_l2[-1], **r)
-    assert r["err_train_logits"] < 1e-3 and abs(loss_c - loss_h) < 1e-4, r            # north_star: 1e-3 fp32
+    assert r["err_train_logits"] < 1e-3 and abs(r["loss_cpu"] - r["loss_hip"]) < 1e-4, r            # north_star: 1e-3 fp32
     assert r["running_mean_rel_max"] < 1e-4 and r["running_var_rel_max"] < 1e-4 and r["head_grad_l2_max"] < 5e-3, r
     for k, (dh, dc) in dist.items():
         assert dh <= 3 * dc + 1e-4, (k, dh, dc)
