@@ -569,10 +569,48 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
     *reinterpret_cast<uint2*>(out + i * 4) = make_uint2(lo, hi);
   }
 }
+// W % 4 == 0, bf16: a thread moves FOUR source pixels -- three aligned 16-byte loads (one per colour plane), four 8-byte stores -- instead
+// of one pixel with three 4-byte loads (256 B per wave-instruction: 164 us for the 154 MB + 108 MB this pass moves = 1.6 TB/s).  Threads
+// W/4 and W/4 + 1 of a row write the left / right zero borders; rows outside the image are zeros throughout.  Block = 64 x 4 rows.
+__global__ __launch_bounds__(256) void stem_pack4_kernel(const float* __restrict__ img, int H, int W, int Hp, int Wp, bf16_t* __restrict__ out) {
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63), hp = blockIdx.y * 4 + (threadIdx.x >> 6), n = blockIdx.z;
+  const int nq = W / 4;
+  if (hp >= Hp || t >= nq + 2) return;
+  uint2* row = reinterpret_cast<uint2*>(out) + ((size_t)n * Hp + hp) * Wp;
+  const int h = hp - 3;
+  const uint2 z = make_uint2(0u, 0u);
+  if (t >= nq) {   // borders: padded columns 0..2, or W + 3 .. Wp - 1
+    const int b = t == nq ? 0 : W + 3, e = t == nq ? 3 : Wp;
+    for (int wp = b; wp < e; ++wp) row[wp] = z;
+    return;
+  }
+  uint2 o[4] = {z, z, z, z};
+  if ((unsigned)h < (unsigned)H) {
+    const float* src = img + ((size_t)n * 3 * H + h) * W + 4 * t;
+    const size_t plane = (size_t)H * W;
+    const f32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src));
+    const f32x4_t g = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + plane));
+    const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(src + 2 * plane));
+    o[0] = make_uint2(f32_to_bf16_bits(r.x) | (f32_to_bf16_bits(g.x) << 16), f32_to_bf16_bits(b.x));
+    o[1] = make_uint2(f32_to_bf16_bits(r.y) | (f32_to_bf16_bits(g.y) << 16), f32_to_bf16_bits(b.y));
+    o[2] = make_uint2(f32_to_bf16_bits(r.z) | (f32_to_bf16_bits(g.z) << 16), f32_to_bf16_bits(b.z));
+    o[3] = make_uint2(f32_to_bf16_bits(r.w) | (f32_to_bf16_bits(g.w) << 16), f32_to_bf16_bits(b.w));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row[4 * t + 3 + i] = o[i];
+}
 template <typename T>
 int stem_pack(const float* img, int N, int H, int W, int Hp, int Wp, T* img4, hipStream_t st) {
   ARG_CHECK(Hp >= H + 6 && Wp >= W + 6 && Wp % 2 == 0, "stem_pack: bad padded size");
   ARG_CHECK(Hp <= 65535 && N <= 65535, "stem_pack: grid %d x %d", Hp, N);
+  if constexpr (sizeof(T) == 2) {
+    static const bool pack4 = [] { const char* v = getenv("MMSKIN_STEM_PACK4"); return !v || atoi(v) != 0; }();
+    if (pack4 && W % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {
+      hipLaunchKernelGGL(stem_pack4_kernel, dim3(ceil_div(W / 4 + 2, 64), ceil_div(Hp, 4), N), dim3(256), 0, st, img, H, W, Hp, Wp, img4);
+      HIP_CHECK_RET(hipGetLastError());
+      return MMSKIN_OK;
+    }
+  }
   hipLaunchKernelGGL(stem_pack_kernel<T>, dim3(ceil_div(Wp, 256), Hp, N), dim3(256), 0, st, img, N, H, W, Hp, Wp, img4);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -789,6 +827,14 @@ int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, cons
   const size_t cells = (size_t)N * PH * PW;
   ARG_CHECK(cells < ((size_t)1 << 32), "stem_pool_bn_bwd_reduce: %zu cells", cells);
   ColGeom g = col_geom(cells, C, DT<T>::EPC);
+  // col_geom aims at ~1000 blocks (25 cells per lane, 12 loads each, two integer divisions per cell): 294 us for the 540 MB the pass
+  // reads.  Four cells per lane instead (6 272 blocks at batch 256): the partial rows go through the two-stage reduction like the
+  // dgrad epilogues' (MMSKIN_STEM_REDUCE_CELLS: cells per lane)
+  static const int cells_per_lane = [] { const char* v = getenv("MMSKIN_STEM_REDUCE_CELLS"); return v ? atoi(v) : 4; }();
+  if (cells_per_lane > 0 && (size_t)g.RL * cells_per_lane < (size_t)g.RB) {
+    g.RB = g.RL * cells_per_lane;
+    g.gx = (int)((cells + g.RB - 1) / g.RB);
+  }
   hipLaunchKernelGGL(stem_pool_bn_bwd_reduce_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, st, dpool, idx, x, scale, shift, H, W, C, PH,
                      PW, cells, g, partial);
   HIP_CHECK_RET(hipGetLastError());
