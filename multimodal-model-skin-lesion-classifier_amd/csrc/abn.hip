@@ -90,3 +90,19 @@ int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, cons
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
+
+// ---- second phase: the BatchNorm-backward sum  sum_m g[m][o] x[m][o]  without x:  x = y W^T  =>  it is  sum_k W[o][k] (g^T y)[o][k],
+// a row-wise dot product of the weight with the S the weight-gradient GEMM has just produced.  grid = C4 blocks, 64 threads.
+__global__ __launch_bounds__(64) void abn_sgx_kernel(const float* __restrict__ S, const float* __restrict__ W, int Cw, float* __restrict__ sgx) {
+  const int o = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < Cw; k += 64) s += abn_wb(W[(size_t)o * Cw + k]) * S[(size_t)o * Cw + k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+  if (threadIdx.x == 0) sgx[o] = s;
+}
+int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStream_t st) {
+  hipLaunchKernelGGL(abn_sgx_kernel, dim3(C4), dim3(64), 0, st, S, W, Cw, sgx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}

@@ -21,6 +21,8 @@ struct Unit {  // conv + batch-norm
   size_t y_off;                  // post-activation output (bytes); for the last unit of a block = block output
   size_t coef_off;               // floats: scale, shift, mean, invstd (4*Cout)
   bool abn = false;              // algebraic BatchNorm backward (abn.hip): expanding 1x1 conv3 of a bottleneck, bf16 plans
+  bool fwd2p = false;            // ... and its raw output x never stored: two-pass forward (statistics, then conv + BatchNorm + residual + ReLU in the
+                                 // epilogue), BatchNorm-backward x sums from the weight-gradient GEMM (blocks without a downsample branch)
   size_t abn_coef_off = 0;       // this unit's copy of cA | cB | cC (3*Cout floats) for the weight-gradient stream
   size_t rows() const { return (size_t)s.N * s.OH() * s.OW(); }
 };
@@ -45,6 +47,7 @@ struct Plan : PlanBase {
       off_coefbwd, off_coefbwd_b, off_dwv, off_red, off_partial_b, off_stat_b, off_red_b;
   size_t off_abn_wd = 0, off_abn_bias = 0, off_abn_S = 0, off_abn_cs = 0;   // algebraic BatchNorm backward scratch
   size_t off_abn_wd2 = 0, off_abn_bias2 = 0;                                 // ... of a stride-1 downsample convolution (its folded weights live beside conv3's)
+  size_t off_abn_sgx = 0, off_abn_slab2 = 0, off_abn_S2 = 0, off_abn_cs2 = 0;   // two-pass units: main-stream weight-gradient scratch
   size_t maxact_bytes = 0, stat_bytes = 0;
 
   int forward(const void* image, const float* norm6, const float* params, float* buffers, unsigned char* ws,
@@ -232,6 +235,21 @@ int build_plan(Plan& p) {
       p.off_abn_cs = carve(cur, (size_t)cw_max * sizeof(float));
       p.off_abn_wd2 = carve(cur, wd_max);
       p.off_abn_bias2 = carve(cur, (size_t)cw_max * sizeof(float));
+      static const int fwd2p_on = [] { const char* v = getenv("MMSKIN_FWD2P"); return v ? atoi(v) : 1; }();
+      size_t slab2 = 0;
+      for (Block& b : p.blocks) {
+        Unit& u = p.units[b.units.back()];
+        if (!fwd2p_on || !u.abn || b.ds >= 0) continue;
+        u.fwd2p = true;
+        const size_t sb = wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin);
+        if (sb > slab2) slab2 = sb;
+      }
+      if (slab2) {
+        p.off_abn_sgx = carve(cur, 1024 * sizeof(float));
+        p.off_abn_slab2 = carve(cur, slab2);
+        p.off_abn_S2 = carve(cur, s_max);
+        p.off_abn_cs2 = carve(cur, (size_t)cw_max * sizeof(float));
+      }
     }
   }
   p.off_slab = carve(cur, slab_max);
@@ -389,13 +407,20 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
       T* x = reinterpret_cast<T*>(ws + u.x_off);
       T* y = reinterpret_cast<T*>(ws + u.y_off);
       int nrows_u = 0;   // statistics row blocks this launch wrote (the launcher picks the tile height)
+      const bool two_pass = training && u.fwd2p && i + 1 == nu && sizeof(T) == 2;
       PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
-           launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, x, training ? stat_sum : nullptr,
+           launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, two_pass ? (T*)nullptr : x, training ? stat_sum : nullptr,
                               training ? stat_sq : nullptr, st, nullptr, &nrows_u));
       if ((rc = bn_coeffs(u, nrows_u))) return rc;
       float* coef = reinterpret_cast<float*>(ws + u.coef_off);
       const int C = u.s.Cout;
-      if (i + 1 < nu) {
+      if (two_pass) {
+        // second pass: the conv again with scale * acc + shift + identity + ReLU (+ the mask byte) in its epilogue -- the raw output
+        // (the block's widest tensor) is neither written nor read: 2T + 2t bytes instead of 4T + t, and the normalisation multiplies the
+        // fp32 accumulator, not a bf16-rounded copy of it
+        FwdFuse f2; f2.mul = coef; f2.bias = coef + C; f2.addend = in; f2.relu = true; f2.mask_out = ws + b.mask_off;
+        PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 0) + (double)u.rows() * C * sizeof(T), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f2));
+      } else if (i + 1 < nu) {
         PROF(K_BN_FWD, 0.0, 2.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
       } else if (b.ds >= 0) {
         Unit& d = p.units[b.ds];
@@ -450,7 +475,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
   // on_branch: the downsample branch on its own stream (own coefficient and reduction scratch)
   // dx == nullptr: finalize only (gamma / beta gradients and the coefficients cA, cB, cC) -- the algebraic path folds the apply
   // into its two GEMMs
-  auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx, bool on_branch = false) -> int {
+  auto bn_backward_fused = [&](Unit& u, const T* dz, const float* part, int nrows, T* dx, bool on_branch = false, const float* sum_dz_x = nullptr) -> int {
     const int C = u.s.Cout;
     float* coef = reinterpret_cast<float*>(ws + u.coef_off);
     const T* x = reinterpret_cast<const T*>(ws + u.x_off);
@@ -463,7 +488,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     struct End { Profiler& pr; hipStream_t s; ~End() { pr.end(s); } } end_guard{p.prof, st};
     if (p.prof.on && dx) p.prof.bytes[K_BN_BWD] += 3.0 * u.rows() * C * sizeof(T);
     if ((r = bn_bwd_finalize(part, nrows, C, (double)u.rows(), params + u.g_off, coef + 2 * C, coef + 3 * C,
-                             grads + u.g_off, grads + u.b_off, kA, cB, cC, red, bs))) return r;
+                             grads + u.g_off, grads + u.b_off, kA, cB, cC, red, bs, -1, false, sum_dz_x))) return r;
     if (!dx) return MMSKIN_OK;
     return bn_bwd_apply<T>(dz, x, nullptr, coef, coef + C, MASK_NONE, kA, cB, cC, dx, nullptr, u.rows(), C, bs);
   };
@@ -574,11 +599,29 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if (p.side.done_valid[2]) HIP_CHECK_RET(hipStreamWaitEvent(p.side.s2, p.side.done[2], 0));   // the last wgrad that read dXd
         if ((rc = bn_backward_fused(p.units[b.ds], g, partial_b, fused_rows, dXd, true))) return rc;
       }
-      if ((rc = bn_backward_fused(ul, g, partial, fused_rows, abn ? nullptr : dX))) return rc;
+      const T* uin3 = nu > 1 ? reinterpret_cast<const T*>(ws + p.units[b.units[nu - 2]].y_off) : in;
+      const float* sgx = nullptr;
+      if (abn && ul.fwd2p) {
+        // two-pass unit: x was never stored.  g^T y first (main stream: the BatchNorm-backward sum of g x is W . (g^T y) row by row)
+        if constexpr (sizeof(T) == 2) {
+          float* S2 = reinterpret_cast<float*>(ws + p.off_abn_S2);
+          p.prof.begin(K_WGRAD, st);
+          rc = launch_wgrad_gram(ul.s.N, ul.s.OH(), ul.s.OW(), ul.s.Cin, ul.s.Cout, g, uin3, reinterpret_cast<float*>(ws + p.off_abn_slab2), S2,
+                                 reinterpret_cast<float*>(ws + p.off_abn_cs2), st);
+          p.prof.end(st);
+          if (p.prof.on) { p.prof.flops[K_WGRAD] += conv_flops(ul.s); p.prof.bytes[K_WGRAD] += conv_bytes(ul.s, sizeof(T)); }
+          if (rc) return rc;
+          if ((rc = abn_sgx(S2, params + ul.w_off, ul.s.Cout, ul.s.Cin, reinterpret_cast<float*>(ws + p.off_abn_sgx), st))) return rc;
+          sgx = reinterpret_cast<const float*>(ws + p.off_abn_sgx);
+        }
+      }
+      if ((rc = bn_backward_fused(ul, g, partial, fused_rows, abn ? nullptr : dX, false, sgx))) return rc;
       if (abn) {   // fold the coefficients into this block's conv3 data-gradient weights; keep a copy for the weight-gradient fix-up
         if constexpr (sizeof(T) == 2) {
           if ((rc = abn_prep(params + ul.w_off, cA, cA + ul.s.Cout, cA + 2 * ul.s.Cout, ul.s.Cout, ul.s.Cin, reinterpret_cast<bf16_t*>(ws + p.off_abn_wd),
                              reinterpret_cast<float*>(ws + p.off_abn_bias), reinterpret_cast<float*>(ws + ul.abn_coef_off), st))) return rc;
+          if (ul.fwd2p && (rc = abn_wgrad_finalize(reinterpret_cast<const float*>(ws + p.off_abn_S2), reinterpret_cast<const float*>(ws + p.off_abn_cs2), params + ul.w_off,
+                                                   reinterpret_cast<const float*>(ws + ul.abn_coef_off), ul.s.Cout, ul.s.Cin, grads + ul.w_off, st))) return rc;
         }
       }
       if (has_ds && !ds_branch) {
@@ -603,7 +646,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
       Unit& u = p.units[b.units[i]];
       const T* uin = i == 0 ? in : reinterpret_cast<const T*>(ws + p.units[b.units[i - 1]].y_off);
       const bool abn_u = abn && i == nu - 1;
-      if (abn_u) { if ((rc = wgrad_abn_async(u, g, uin))) return rc; }
+      if (abn_u) { if (!u.fwd2p && (rc = wgrad_abn_async(u, g, uin))) return rc; }   // (two-pass units: done above, on this stream)
       else if ((rc = wgrad_async(u, dxi, uin))) return rc;
       if (i > 0) {
         // dgrad writes the gradient of unit i-1's ReLU output; its epilogue applies that ReLU's mask and
@@ -648,7 +691,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if (bi > 0) {   // gin is the gradient of the previous block's output: fuse that block's final BN reduce
           Block& pb = p.blocks[bi - 1];
           Unit& pu = p.units[pb.units.back()];
-          f.mask_bits = ws + pb.mask_off; f.x = ws + pu.x_off; f.partial = partial;
+          f.mask_bits = ws + pb.mask_off; f.x = pu.fwd2p ? nullptr : ws + pu.x_off; f.partial = partial;   // two-pass unit: no raw output to take sums against
           if (pb.ds >= 0) { f.x2 = ws + p.units[pb.ds].x_off; f.partial_b = partial_b; }
           fp = &f;
         }

@@ -66,6 +66,9 @@ struct ConvGemmArgs {
   // 128-row kernels only.
   const void* in2;
   int K1, pitch2_shift;
+  const float* ep_mul;     // light-epilogue launches: per-output-channel multiplier applied to the accumulator BEFORE bias / addend (train-mode BatchNorm scale)
+  uint8_t* ep_mask_out;    // light-epilogue launches: also write the ReLU mask of the stored tile, one byte per 16-byte chunk, bit e = (stored value e > 0)
+                           // (the forward's second pass of a two-pass conv + BatchNorm + residual + ReLU, backbone.hip)
   int ablate;          // -DMMSKIN_ABLATE builds only (`make ablate`): bit0 skip A DMA, bit1 skip B DMA, bit2 skip MFMA, bit3 skip stores; always 0 in the production library
 #ifdef MMSKIN_ABLATE
   unsigned long long* stamps;   // in-kernel phase stamps (scripts/conv_stamps.py): [workgroup][8] s_memtime values, or null
@@ -122,6 +125,8 @@ struct FwdFuse {
   const float* res_f32 = nullptr; // [rows][Cout] fp32
   float drop_p = 0.f;
   uint64_t seed = 0, offset = 0;
+  uint8_t* mask_out = nullptr;    // write the ReLU mask of the result (one byte per 16-byte chunk) beside it
+  const float* mul = nullptr;     // [Cout] fp32: out = act(acc * mul + bias + addend)
 };
 template <typename T>
 int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, float* stat_sum,
@@ -205,3 +210,4 @@ int launch_wgrad3_ring(const ConvShape& s, const bf16_t* dout, const bf16_t* in,
 int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, int C4, int Cw, bf16_t* wd, float* bias, float* coef_copy,
              hipStream_t st);
 int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st);
+int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStream_t st);

@@ -552,10 +552,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   //   4 addend + 1-bit ReLU mask + x and the sums                               (dgrads into a residual block output)
   //   5 = 4 + x2 and its sums                                                   (... whose block has a downsample BatchNorm too)
   //   6 = 2 + layer scale, dropout and an fp32 residual stream                  (Linear layers of the frozen transformer encoders)
-  constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5, HAS_BR = EPI == 1 || EPI == 2 || EPI == 6, HAS_MY = EPI == 1;
+  //   7 addend + 1-bit ReLU mask, sums of the masked values only (dgrads into a residual block output whose BatchNorm-backward
+  //     x sums come from the weight-gradient GEMM instead: the algebraic path's second phase, abn.hip)
+  constexpr bool HAS_ADD = EPI == 1 || EPI == 2 || EPI == 4 || EPI == 5 || EPI == 7, HAS_BR = EPI == 1 || EPI == 2 || EPI == 6, HAS_MY = EPI == 1;
   constexpr bool HAS_TR = EPI == 6;
   constexpr bool HAS_BIAS = HAS_BR || EPI == 3;   // profile 3 + bias: the algebraic BatchNorm-backward dgrad (constant row of the folded coefficients)
-  constexpr bool HAS_MB = EPI == 1 || EPI == 4 || EPI == 5, HAS_X = EPI == 1 || EPI >= 3, HAS_X2 = EPI == 1 || EPI == 5;
+  constexpr bool HAS_MB = EPI == 1 || EPI == 4 || EPI == 5 || EPI == 7, HAS_X = EPI == 1 || (EPI >= 3 && EPI != 7), HAS_X2 = EPI == 1 || EPI == 5;
+  constexpr bool HAS_MO = EPI == 2;   // light profile: optional mask byte out and per-channel multiplier (two-pass BatchNorm forward)
   const unsigned char* add_b = HAS_ADD ? reinterpret_cast<const unsigned char*>(p.addend) : nullptr;
   const unsigned char* my_b = HAS_MY ? reinterpret_cast<const unsigned char*>(p.ep_mask_y) : nullptr;
   const uint8_t* mb_b = HAS_MB ? p.ep_mask_bits : nullptr;
@@ -566,6 +569,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   const bool do_relu = HAS_BR && p.ep_relu == 1;
   const bool do_gelu = HAS_BR && p.ep_relu == 2;          // exact (erf) GELU: the MLP of the transformer blocks
   float* out_f32 = HAS_BR ? p.out_f32 : nullptr;         // Linear layers at the fp32 op boundary: widen while storing
+  const bool has_mul = HAS_MO && p.ep_mul != nullptr;
+  float emul[EPC];
+  if (has_mul) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) emul[e] = p.ep_mul[n0 + cj * EPC + e];
+  }
   float ebias[EPC];
   if (has_bias) {
 #pragma unroll
@@ -630,6 +639,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       const int row = r0 + (grp + k) * ROWS_PER_PASS;
       Chunk<T> v;
       v.load(Cs + row * CPITCH + cj * 16);
+      if constexpr (HAS_MO) {
+        if (has_mul) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v.v[e] *= emul[e];
+        }
+      }
       if (add_b) {
         Chunk<T> ad;
         ad.from_raw(q_ad[k]);
@@ -704,14 +719,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
           for (int e = 0; e < EPC; ++e) ssb[e] += vr.v[e] * x2v.v[e];
         }
       } else {
+        if constexpr (EPI == 7 && sizeof(T) == 2) {   // sums of the masked gradient as stored (rounded), like the profiles that also read x
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
+          for (int e = 0; e < EPC; ++e) ssum[e] += bf16_bits_to_f32(f32_to_bf16_bits(v.v[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { ssum[e] += v.v[e]; ssq[e] += v.v[e] * v.v[e]; }
+        }
+      }
+      if constexpr (HAS_MO) {
+        if (p.ep_mask_out) {
+          uint32_t bits = 0;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) bits |= (from_f32<T>(v.v[e]) != 0 && v.v[e] > 0.f ? 1u : 0u) << e;   // bit = (stored value > 0), as bn_apply writes it
+          p.ep_mask_out[goffs[k] >> 4] = (uint8_t)bits;
+        }
       }
       if (out_f32) {
         float* dst = out_f32 + goffs[k] / sizeof(T);
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(v.v[e], v.v[e + 1], v.v[e + 2], v.v[e + 3]);
-      } else if (!(abl & 8)) v.store(out_b + goffs[k]);
+      } else if (!(abl & 8) && out_b) v.store(out_b + goffs[k]);   // out == nullptr: statistics-only pass
     }
   }
   STAMP(6);
@@ -805,7 +833,7 @@ static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, Pi
   static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
   static const int mintiles = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINTILES"); return v ? atoi(v) : 192; }();
   static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
-  if (!on || !a.pipe_ok || a.in2 || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
+  if (!on || !a.pipe_ok || a.in2 || prof == 7 || a.ep_mask_out || a.ep_mul || !a.out || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
       a.C % 64 != 0 || a.ncls < 1)
     return false;
   if (tr && (heavy || a.addend || a.stat_sum || !a.out_f32)) return false;   // the transformer-residual epilogue's own contract (checked below)
@@ -844,7 +872,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   a.stamps = g_conv_stamps;
 #endif
   const bool tr = a.ep_gamma || a.res_f32 || a.ep_drop_p > 0.f;   // transformer-residual epilogue
-  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32 || tr;
+  const bool epi = a.addend || a.ep_mask_y || a.ep_mask_bits || a.ep_x || a.ep_bias || a.ep_relu || a.out_f32 || a.ep_mul || a.ep_mask_out || tr;
   // Single-buffer variant (3-4 workgroups per CU) whenever the launch has enough workgroups to use the
   // extra residency: measured on the ResNet-50 shape mix (scripts/conv_mix.py) it wins for every layer
   // with more than ~2.5 workgroups per CU and loses for the 392-workgroup layer-4 launches.
@@ -862,6 +890,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   if (profiles_on && heavy && !a.ep_mask_y && !a.ep_relu) {
     if (a.ep_x && !a.addend && !a.ep_mask_bits && !a.ep_x2) prof = 3;   // (+ optional bias)
     else if (!a.ep_bias && a.ep_x && a.ep_mask_bits && !a.ep_scale) prof = a.ep_x2 ? 5 : 4;
+    else if (!a.ep_bias && !a.ep_x && !a.ep_x2 && a.ep_mask_bits && !a.ep_scale) prof = 7;
   }
   if constexpr (sizeof(T) == 2) {
     PipeChoice pc;
@@ -878,7 +907,7 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (big_min_k > 0 && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
+    if (big_min_k > 0 && a.out && !a.ep_mask_out && !a.ep_mul && a.wrow >= big_min_k && a.ncls == 1 && !heavy && !a.stat_sum && !a.addend && a.Cout % 256 == 0 && a.ep_relu != 2 &&
         a.cls[0].mblk_start == 0 && a.cls[0].ntaps == 1 && a.Sy == 1 && a.Sx == 1 && a.OS == 1) {   // plain GEMMs only (what the tests cover)
       const int mb = ceil_div(a.cls[0].rows, 256), nb = a.Cout / 256;
       if (mb * nb >= 224) {
@@ -898,10 +927,10 @@ static int dispatch_conv_gemm(ConvGemmArgs& a, hipStream_t st) {
   }
   if (a.Cout % 128 == 0) {
     a.nblk_n = a.Cout / 128;
-    return !epi ? GO(128, 0) : (!heavy ? GO(128, 2) : (prof == 3 ? GO(128, 3) : (prof == 4 ? GO(128, 4) : (prof == 5 ? GO(128, 5) : GO(128, 1)))));
+    return !epi ? GO(128, 0) : (!heavy ? GO(128, 2) : (prof == 3 ? GO(128, 3) : (prof == 4 ? GO(128, 4) : (prof == 5 ? GO(128, 5) : (prof == 7 ? GO(128, 7) : GO(128, 1))))));
   }
   a.nblk_n = a.Cout / 64;
-  return !epi ? GO(64, 0) : (!heavy ? GO(64, 2) : (prof == 3 ? GO(64, 3) : (prof == 4 ? GO(64, 4) : (prof == 5 ? GO(64, 5) : GO(64, 1)))));
+  return !epi ? GO(64, 0) : (!heavy ? GO(64, 2) : (prof == 3 ? GO(64, 3) : (prof == 4 ? GO(64, 4) : (prof == 5 ? GO(64, 5) : (prof == 7 ? GO(64, 7) : GO(64, 1))))));
 #undef GO
 }
 
@@ -924,6 +953,7 @@ int launch_conv_fwd(const ConvShape& s, const T* in, const T* w_staged, T* out, 
   if (fuse) {
     a.ep_bias = fuse->bias; a.addend = fuse->addend; a.ep_relu = fuse->gelu ? 2 : (fuse->relu ? 1 : 0); a.out_f32 = fuse->out_f32;
     a.ep_gamma = fuse->gamma; a.res_f32 = fuse->res_f32; a.ep_drop_p = fuse->drop_p; a.ep_seed_mix = mix64(fuse->seed); a.ep_offset = fuse->offset;
+    a.ep_mask_out = fuse->mask_out; a.ep_mul = fuse->mul;
   }
   a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = s.Cout;
   a.N = s.N; a.IH = s.H; a.IW = s.W; a.C = s.Cin; a.Cpitch = s.Cin;

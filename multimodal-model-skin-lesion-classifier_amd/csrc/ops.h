@@ -42,7 +42,8 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                     float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad = -1,
-                    bool accumulate_bc = false);   // accumulate_bc: cB / cC are ADDED to (running sums over the consumers of one input)
+                    bool accumulate_bc = false,    // accumulate_bc: cB / cC are ADDED to (running sums over the consumers of one input)
+                    const float* sum_dz_x = nullptr);   // [C]: use this as sum dz*x instead of the partial rows' second half (abn.hip, second phase)
 // dx = cA*dz + cB*x + cC ; optionally also writes dz (masked dy) to dz_out
 template <typename T>
 int bn_bwd_apply(const T* dy, const T* x, const T* ymask, const float* scale, const float* shift,

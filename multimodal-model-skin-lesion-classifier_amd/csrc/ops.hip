@@ -439,7 +439,7 @@ template <typename IN, int RL = 4>
 __global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
-                                       float* cA, float* cB, float* cC, int n_grad, int acc_bc) {
+                                       float* cA, float* cB, float* cC, int n_grad, int acc_bc, const float* __restrict__ s2_override = nullptr) {
   __shared__ double red[2][RL][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -462,6 +462,7 @@ __global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __re
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
     for (int i = 0; i < RL; ++i) { s1 += red[0][i][cx]; s2 += red[1][i][cx]; }
+    if (s2_override) s2 = (double)s2_override[c];
     double mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.0;
     double dg = is * (s2 - mu * s1);   // sum dz * xhat
     if (dgamma && c < n_grad) dgamma[c] = (float)dg;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __re
 
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
-                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad, bool accumulate_bc) {
+                    float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad, bool accumulate_bc, const float* sum_dz_x) {
   if (n_grad < 0) n_grad = C;
   const int acc_bc = accumulate_bc ? 1 : 0;
   if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
@@ -484,13 +485,13 @@ int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const 
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
   } else if (nrows > 64) {
     hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc);
+                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
   }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;

@@ -20,9 +20,15 @@ def resnet50():
 blocks = resnet50()
 stem = ("stem", dict(Mo=N * 112 * 112, Mi=N * 224 * 224, Cin=3, Cout=64, taps=49))
 fwd = [stem]
+import os
+FWD2P = os.environ.get("MMSKIN_FWD2P", "1") != "0" and os.environ.get("MMSKIN_ABN", "1") != "0"
 for u, ds in blocks:
     if ds: fwd.append(ds)
     fwd += u
+    # two-pass forward (backbone.hip): conv3 of a layer1 / layer2 block without a downsample branch runs twice -- statistics only, then
+    # conv + BatchNorm + residual + ReLU in the epilogue (the "c3" row is the statistics pass, "c3+bn" the second one)
+    if FWD2P and not ds and u[2][1]["Cin"] <= 128:
+        fwd.append((u[2][0] + "+bn", u[2][1]))
 bwd = []   # per block, last to first: conv3, conv2, (downsample), conv1 -- the plan's dgrad order
 for u, ds in reversed(blocks):
     bwd += [u[2], u[1]] + ([ds] if ds else []) + [u[0]]
@@ -69,7 +75,7 @@ for i, ((name, d), r) in enumerate(zip(fwd + bwd, conv)):
     kn = "layer-1 3x3" if "conv3x3_c64" in r["Kernel_Name"] else ("pipelined" if int(r["Workgroup_Size_X"]) == 512 else "128-row")
     print(f"{kind} {name:10s} {M:8d} {Nn:5d} {K:5d} {us:8.1f} {fl / us / 1e6:7.0f} {hb:8.1f} {mf:8.1f} {us / max(hb, mf):6.2f}  {kn} x{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}")
 print(f"forward {tot['F'] / 1e3:.3f} ms, dgrad {tot['D'] / 1e3:.3f} ms per step (production: beside the side stream's weight-gradient GEMMs)")
-wg = [r for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"]]
+wg = [r for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"]]
 nw = 53
 wg = wg[-nw:]
 if len(wg) == nw:
