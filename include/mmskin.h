@@ -108,6 +108,16 @@ int mmskin_conv2d_forward(const float* x, const float* w, float* y, int N, int C
 int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, float* dx, float* dw, int N, int Cin,
                            int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype, void* workspace,
                            void* stream);
+/* bf16 data gradient with the consumer unit's BatchNorm-backward prologue fused into the epilogue (what the ResNet plan launches for every
+ * conv -> BatchNorm -> ReLU unit, csrc/conv_gemm.hip profile 3 / csrc/conv3x3_c64.hip): dz = dgrad(dy) * (xc * scale + shift > 0) and
+ * the per-row-block partial sums [rows][2][Cin] of dz and dz * xc.  Replaces conv_backward(input) + the ReLU / BatchNorm-backward
+ * reductions autograd runs after it (train_pad_20.py:112).  Workspace: mmskin_conv2d_workspace_bytes. */
+int mmskin_conv2d_dgrad_fused_rows(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad);
+int mmskin_conv2d_dgrad_fused(const float* dy, const float* w, const float* xc, const float* scale, const float* shift, float* dz,
+                              float* partial, int* rows_written, int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                              int pad, void* workspace, void* stream);
+/* launches of the layer-1 all-taps 3x3 kernel (csrc/conv3x3_c64.hip) since load */
+int64_t mmskin_conv3x3_c64_launches(void);
 /* timing helper for kernel tuning: average microseconds of the forward conv kernel over `iters` launches
  * on NHWC buffers carved from `workspace` (>= conv2d_workspace_bytes; contents irrelevant) */
 double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,

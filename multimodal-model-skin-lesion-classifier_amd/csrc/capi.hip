@@ -264,6 +264,40 @@ int mmskin_conv2d_backward(const float* dy, const float* x, const float* w, floa
            conv_bwd_op<bf16_t>(dy, x, w, dx, dw, s, workspace, st));
 }
 
+/* Data gradient with the CONSUMER's BatchNorm-backward prologue fused into the epilogue (DgradFuse, profile 3: what the plan launches
+ * for every conv -> BatchNorm -> ReLU unit): dz = dgrad(dy) * (xc * scale + shift > 0), plus the partial sums of dz and dz * xc per
+ * row block.  xc [N,Cin,H,W] is the raw BatchNorm input of the unit that produced this conv's input; dz [N,Cin,H,W];
+ * partial [rows][2][Cin] (rows <= mmskin_conv2d_dgrad_fused_rows(...)), *rows_written = rows the launch produced. */
+int mmskin_conv2d_dgrad_fused_rows(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad) {
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  const int a = conv_dgrad_partial_rows(s);
+  return a > N ? a : N;
+}
+int mmskin_conv2d_dgrad_fused(const float* dy, const float* w, const float* xc, const float* scale, const float* shift, float* dz,
+                              float* partial, int* rows_written, int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                              int pad, void* workspace, void* stream) {
+  ARG_CHECK(dy && w && xc && scale && shift && dz && partial && rows_written && workspace, "conv2d_dgrad_fused: null argument");
+  ConvShape s = {N, H, W, Cin, Cout, kh, kw, stride, pad};
+  hipStream_t st = (hipStream_t)stream;
+  Carver c(workspace);
+  typedef bf16_t T;
+  StageDesc* table = c.take<StageDesc>(1);
+  T* xh = c.take<T>((size_t)N * H * W * Cin);
+  T* wf = c.take<T>((size_t)Cout * Cin * kh * kw);
+  T* yh = c.take<T>((size_t)N * s.OH() * s.OW() * Cout);
+  T* wd = c.take<T>((size_t)Cout * Cin * kh * kw);
+  T* dxh = c.take<T>((size_t)N * H * W * Cin);
+  int rc;
+  if ((rc = nchw_to_nhwc<T>(dy, N, Cout, s.OH(), s.OW(), yh, st))) return rc;
+  if ((rc = nchw_to_nhwc<T>(xc, N, Cin, H, W, xh, st))) return rc;
+  if ((rc = stage_one<T>(w, Cout, Cin, kh * kw, false, wf, wd, table, st))) return rc;
+  DgradFuse f;
+  f.x = xh; f.scale = scale; f.shift = shift; f.partial = partial;
+  if ((rc = launch_conv_dgrad<T>(s, yh, wd, dxh, (const T*)nullptr, st, &f))) return rc;
+  *rows_written = f.rows_written;
+  return nhwc_to_nchw<T>(dxh, N, Cin, H, W, dz, st);
+}
+
 /* timing helper: runs the forward conv kernel `iters` times on NHWC buffers already resident in the
  * workspace (contents irrelevant) and returns the average microseconds per launch. */
 double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,

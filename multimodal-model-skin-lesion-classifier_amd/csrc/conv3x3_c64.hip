@@ -290,12 +290,16 @@ bool conv3x3_c64_takes(const ConvShape& s, bool bf16) {
          s.H >= 8 && s.N >= min_n;
 }
 
+static int64_t g_c64_launches = 0;
+extern "C" int64_t mmskin_conv3x3_c64_launches(void) { return g_c64_launches; }
+
 // forward: w_staged [cout][tap][cin]; stats (optional): one row per image, *stat_rows_out = N
 int launch_conv3x3_c64_fwd(const ConvShape& s, const bf16_t* in, const bf16_t* w_staged, bf16_t* out, float* stat_sum, float* stat_sq,
                            int stat_stride, hipStream_t st) {
   C3Args a = {};
   a.in = in; a.w = w_staged; a.out = out; a.stat_sum = stat_sum; a.stat_sq = stat_sq; a.stat_stride = stat_stride;
   a.N = s.N; a.H = s.H; a.W = s.W;
+  ++g_c64_launches;
   return launch_one<7, 0, 0>(a, st);
 }
 
@@ -305,6 +309,7 @@ int launch_conv3x3_c64_dgrad(const ConvShape& s, const bf16_t* dout, const bf16_
   C3Args a = {};
   a.in = dout; a.w = wt_staged; a.out = din;
   a.N = s.N; a.H = s.H; a.W = s.W;
+  ++g_c64_launches;
   if (fuse) {
     a.ep_x = reinterpret_cast<const bf16_t*>(fuse->x); a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
     a.stat_sum = fuse->partial; a.stat_sq = fuse->partial + 64; a.stat_stride = 128;

@@ -60,6 +60,9 @@ _SIGNATURES = {
     "mmskin_conv2d_backward": (_i, [_P] * 5 + [_i] * 10 + [_P, _P]),
     "mmskin_conv_pipe_launches": (_i64, []),
     "mmskin_wgrad_ring_launches": (_i64, []),
+    "mmskin_conv3x3_c64_launches": (_i64, []),
+    "mmskin_conv2d_dgrad_fused_rows": (_i, [_i] * 9),
+    "mmskin_conv2d_dgrad_fused": (_i, [_P] * 8 + [_i] * 9 + [_P, _P]),
     "mmskin_wgrad3_ring_launches": (_i64, []),
     "mmskin_abn_workspace_bytes": (_i64, [_i] * 5),
     "mmskin_abn_backward": (_i, [_P] * 6 + [_i] * 5 + [_P, _P, _P, _P]),

@@ -111,6 +111,9 @@ import sys
 sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
 import torch, torch.nn.functional as F
 from gpu_util import DEV, conv_backward, conv_forward, rel_err
+from mmskin import _lib
+lib = _lib.load()
+EXPECT_C64 = %(expect)d
 g = torch.Generator().manual_seed(13)
 for (N, H) in [(3, 56), (2, 8), (1, 12), (2, 20)]:
     x = torch.randn(N, 64, H, 56, generator=g)
@@ -119,8 +122,10 @@ for (N, H) in [(3, 56), (2, 8), (1, 12), (2, 20)]:
     y_ref = F.conv2d(xr, wr, stride=1, padding=1)
     dy = torch.randn(y_ref.shape, generator=g)
     y_ref.backward(dy)
+    n0 = lib.mmskin_conv3x3_c64_launches()
     y = conv_forward(x.to(DEV), w.to(DEV), 1, 1, "bf16")
     dx, dw = conv_backward(dy.to(DEV), x.to(DEV), w.to(DEV), 1, 1, "bf16")
+    assert lib.mmskin_conv3x3_c64_launches() - n0 == 2 * EXPECT_C64, "layer-1 3x3 kernel selection"
     ef, eb = rel_err(y, y_ref), rel_err(dx, xr.grad)
     print("CASE", (N, H), "fwd", ef, "dgrad", eb, flush=True)
     assert ef < 5e-2 and eb < 5e-2
@@ -139,6 +144,63 @@ def test_layer1_3x3_all_taps_kernel_matches_torch(on):
     tapped kernel (the A/B knob must keep working).  Tolerance: the bf16 kernel bound of test_gpu_kernels.py."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MMSKIN_CONV3X3_C64=on, MMSKIN_CONV3X3_C64_MIN_N="1")
-    code = C3_CODE % dict(tests=os.path.join(root, "tests"), root=root, pkg=os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"))
+    code = C3_CODE % dict(tests=os.path.join(root, "tests"), root=root, pkg=os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"), expect=int(on))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+
+
+FUSED_CODE = r'''
+import sys, ctypes
+sys.path[:0] = [%(tests)r, %(root)r, %(pkg)r]
+import torch, torch.nn.functional as F
+from gpu_util import DEV, rel_err, ws
+from mmskin import _lib
+from mmskin._lib import call, ptr, stream
+lib = _lib.load()
+rb = lambda t: t.bfloat16().float()
+g = torch.Generator().manual_seed(21)
+# N, Cin, H, W, Cout, k, stride, pad, layer-1 kernel expected
+for (N, Cin, H, W, Cout, k, s, p, c64) in [(3, 64, 56, 56, 64, 3, 1, 1, %(expect)d), (2, 64, 14, 14, 256, 1, 1, 0, 0), (2, 128, 12, 12, 128, 3, 1, 1, 0), (2, 256, 9, 11, 128, 1, 1, 0, 0)]:
+    x_in = torch.randn(N, Cin, H, W, generator=g)
+    w = rb(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = rb(torch.randn(N, Cout, OH, OW, generator=g))
+    xc = rb(torch.randn(N, Cin, H, W, generator=g))                      # raw BatchNorm input of the unit that produced this conv's input
+    scale = torch.rand(Cin, generator=g) + 0.5; shift = torch.randn(Cin, generator=g) * 0.3
+    xin = x_in.double().requires_grad_(True)
+    F.conv2d(xin, w.double(), stride=s, padding=p).backward(dy.double())
+    mask = (xc.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) > 0
+    dz_ref = xin.grad * mask
+    rows = lib.mmskin_conv2d_dgrad_fused_rows(N, Cin, H, W, Cout, k, k, s, p)
+    dz = torch.empty(N, Cin, H, W, device=DEV); part = torch.zeros(rows, 2, Cin, device=DEV)
+    nw = ctypes.c_int(0)
+    wsp = ws(lib.mmskin_conv2d_workspace_bytes(N, Cin, H, W, Cout, k, k, s, p))
+    dev = [t.to(DEV) for t in (dy, w, xc, scale, shift)]
+    n0 = lib.mmskin_conv3x3_c64_launches()
+    call("mmskin_conv2d_dgrad_fused", *[ptr(t) for t in dev], ptr(dz), ptr(part), ctypes.addressof(nw), N, Cin, H, W, Cout, k, k, s, p, ptr(wsp), stream())
+    torch.cuda.synchronize()
+    assert lib.mmskin_conv3x3_c64_launches() - n0 == c64, "kernel selection"
+    e = rel_err(dz, dz_ref)
+    # the sums are taken on the STORED (bf16) dz: compare with sums of the returned dz, and with the exact ones loosely
+    sums = part[: nw.value].double().sum(0).cpu()
+    dzs = dz.double().cpu()
+    s1, s2 = dzs.sum((0, 2, 3)), (dzs * xc.double()).sum((0, 2, 3))
+    e1 = float((sums[0] - s1).abs().max() / (s1.abs().max() + 1e-30)); e2 = float((sums[1] - s2).abs().max() / (s2.abs().max() + 1e-30))
+    print("CASE", (N, Cin, H, W, Cout, k), "dz", e, "sum dz", e1, "sum dz x", e2, "rows", nw.value, flush=True)
+    ok = ((dz.double().cpu() - dz_ref).abs() <= dz_ref.abs() * 2.0 ** -8 + 1e-5 * float(dz_ref.pow(2).mean().sqrt())).all()
+    assert bool(ok), "dz off by more than half a bf16 ulp"
+    assert e1 < 1e-4 and e2 < 1e-4, (e1, e2)
+'''
+
+
+@pytest.mark.parametrize("on", ["1", "0"])
+def test_dgrad_with_fused_batchnorm_backward_epilogue(on):
+    """The data gradient with the consumer's BatchNorm-backward prologue in its epilogue (mask from x * scale + shift, sums of dz and
+    dz * x per row block: profile 3 of csrc/conv_gemm.hip and its twin in csrc/conv3x3_c64.hip), op level through
+    mmskin_conv2d_dgrad_fused -- until round 4 only the ResNet end-to-end tests reached it (ADVICE r03).  dz: every element within half
+    a bf16 ulp of the masked fp64 gradient; the partial rows must sum to the column sums of the dz that was stored (1e-4)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MMSKIN_CONV3X3_C64=on, MMSKIN_CONV3X3_C64_MIN_N="1")
+    code = FUSED_CODE % dict(tests=os.path.join(root, "tests"), root=root, pkg=os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"), expect=int(on))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]

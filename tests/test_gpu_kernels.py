@@ -360,6 +360,47 @@ assert errs[0] > 1e-5      # really the bf16 path (outputs rounded to bf16), not
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_linear_bf16_grouped_tile_order():
+    """The grouped tile order of large-weight Linear GEMMs (csrc/conv_gemm.hip launch_cfg: groups of 8 row blocks x all column blocks, on
+    for weights above 2 MB with >= 16 row blocks and >= 4 column blocks -- BEiT / BERT fc1, fc2, qkv and their dx GEMMs): M = 19 x 128 rows
+    (the last group is ragged: 19 % 8 = 3), K = 1024, N = 2048 in bf16-operand mode, forward and backward, against torch on bf16-rounded
+    inputs AND bit-for-bit against the same launches with MMSKIN_GEMM_GROUP_M=0 (the remap only reorders tiles).  Both knobs
+    are read once per process -> two fresh interpreters, tensors exchanged through a file."""
+    import subprocess, sys, tempfile
+    code = r'''
+import sys, os
+sys.path[:0] = [%r, %r]
+import torch, torch.nn.functional as F
+from mmskin import ops
+g = torch.Generator().manual_seed(5)
+M, K, N = 19 * 128, 1024, 2048
+rb = lambda t: t.bfloat16().float()
+x = rb(torch.randn(M, K, generator=g)); w = rb(torch.randn(N, K, generator=g) / K ** 0.5); b = torch.randn(N, generator=g)
+dy = rb(torch.randn(M, N, generator=g))
+xr, wr, br = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+y_ref = F.linear(xr, wr, br); y_ref.backward(dy.double())
+xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+y = ops.linear(xd, wd, bd, False); y.backward(dy.cuda())
+def l2(a, r): return float((a.cpu().double() - r.double()).norm() / r.double().norm())
+errs = [l2(y, y_ref), l2(xd.grad, xr.grad), l2(wd.grad, wr.grad), l2(bd.grad, br.grad)]
+print("ERRS", errs)
+assert all(e < 5e-3 for e in errs), errs
+torch.save([t.detach().cpu() for t in (y, xd.grad, wd.grad, bd.grad)], sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for gm in ("8", "0"):
+            f = os.path.join(td, f"g{gm}.pt")
+            env = dict(os.environ, MMSKIN_LINEAR_DTYPE="bf16", MMSKIN_GEMM_GROUP_M=gm)
+            r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "multimodal-model-skin-lesion-classifier_amd")), f],
+                               env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            outs.append(torch.load(f, weights_only=True))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), "grouped and plain tile orders differ"
+
+
 @pytest.mark.parametrize("blocks", ["3", "7"])
 def test_wgrad3x3_multi_stage_splits(blocks):
     """All-taps 3x3 weight gradient with few workgroups (MMSKIN_WGRAD3_BLOCKS, read once -> fresh process): every split
