@@ -669,7 +669,7 @@ def _flash_ok(q, k, v, mask_add, bias, bh):
             and not _needs_grad(q, k, v, bias) and all(t.stride(-1) == 1 for t in (q, k, v))):
         return False
     # the kernel's grid is (query tiles, batch * heads): batch * heads <= 65535 (flash_attn.hip ARG_CHECK); larger launches (DaViT
-    # window attention on >= 342 images: 64 windows x 3 heads each) take the rows / unfused path instead of raising.  q is
+    # window attention on >= 342 images: 64 windows x 3 heads each) take the rows / unfused path instead of raising
     return bh <= 65535
 
 
@@ -1078,7 +1078,8 @@ class LinearGeluFn(torch.autograd.Function):
         dw = torch.empty_like(w) if need_w else None
         db = torch.empty(N, device=dh.device, dtype=torch.float32) if need_b else None
         # off the bf16-operand large-GEMM path (head.hip: linear_big / linear_big_padded) the C side applies gelu'(z) in a pass of its own
-        fused = get_linear_dtype() == "bf16" and M >= 2048 and K % 8 == 0 and N % 8 == 0 and K >= 32 and N >= 32
+        # (mmskin_linear_x16_pitch(M, K, N) > 0 IS that predicate, asked of the library instead of re-derived here: ADVICE r03)
+        fused = _lib.load().mmskin_linear_x16_pitch(M, K, N) > 0
         scratch = None if fused else torch.empty_like(dh2)
         if ctx.kept:
             call("mmskin_linear_backward_keep", ptr(dh2), ptr(xs), ptr(w), None, ptr(z), ptr(scratch), ptr(dx), ptr(dw), ptr(db), M, K, N, stream())
