@@ -383,9 +383,28 @@ def main():
     loss_val = float(loss.detach())
 
     roofline, plan = None, None
-    if rank == 0 and not args.no_roofline and not args.infer:
+    if not args.no_roofline and not args.infer:
         enc = model.image_encoder.features if hasattr(model.image_encoder, "classifier") and hasattr(model.image_encoder.features, "_plans") else model.image_encoder
         plan = next(iter(enc._plans.values())) if hasattr(enc, "_plans") else None
+    # N > 1: the kernel-class times of rank 0 WITH the collectives in flight -- every rank runs the same three extra (untimed) steps, rank 0
+    # with the class timers on -- so that a first multi-GPU line separates RCCL contention from straggling (the pass below is the same
+    # thing without any collective)
+    classes_dp = None
+    if world > 1 and plan is not None:
+        lib = _lib.load()
+        if rank == 0:
+            lib.mmskin_backbone_profile_enable(plan.handle, 1)
+        for _ in range(3):
+            step()
+        fence()
+        if rank == 0:
+            ms, fl, by = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)()
+            ln = (ctypes.c_int64 * 7)()
+            _lib.check(lib.mmskin_backbone_profile_read(plan.handle, ms, fl, by, ln))
+            lib.mmskin_backbone_profile_enable(plan.handle, 0)
+            classes_dp = {CLASS_NAMES[i]: round(ms[i] / 3, 3) for i in range(7)}
+    if rank != 0:
+        plan = None
     if plan_missing := (rank == 0 and not args.no_roofline and not args.infer and plan is None):
         roofline = {"note": "this workload's image encoder is a composition of HIP ops without a plan executor: no per-class timers"}
     if rank == 0 and not args.no_roofline and not args.infer and not plan_missing:
@@ -489,6 +508,10 @@ def main():
         if world > 1:   # what a first multi-GPU line needs to be diagnosable: the spread over ranks and the exchange volume
             out["dp"] = {"ms_per_step_over_ranks": rank_ms, "allreduce_bytes_per_step_per_rank": int(reduced[0]),
                          "overlap": sync is not None, "grad_segments_in_flight": dp.max_inflight_segments() if sync is not None else 0,
+                         "segment_lag": dp.segment_lag() if sync is not None else None,
+                         # rank 0's kernel-class ms per step with the all-reduces in flight (class timers serialise the weight-gradient
+                         # stream onto the main one) against roofline.classes, the same pass without any collective
+                         "class_ms_with_collectives": classes_dp,
                          "backend": args.backend}
         if world == 1 and not args.no_cpu_baseline and not args.infer:
             try:

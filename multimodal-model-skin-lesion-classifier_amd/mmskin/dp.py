@@ -31,6 +31,16 @@ def max_inflight_segments():
     return max(1, int(os.environ.get("MMSKIN_DP_STREAMS", "2")))
 
 
+def segment_lag():
+    """MMSKIN_DP_LAG (default 0): the all-reduce of gradient segment i starts only when segment i + lag has ALSO been completed by
+    backward (clamped to the last segment), i.e. it runs `lag` segments later instead of right beside the weight-gradient GEMMs of the
+    next segment.  On one GPU every concurrent HBM consumer beside the main chain and the weight-gradient stream costs the main chain
+    about what it moves (profiles/r04_experiments.txt (3)); whether RCCL's kernels are such a consumer on the 8-GPU node is what the first
+    scaling run has to show -- lag = number of segments (4 for ResNet) queues every all-reduce behind the whole backward."""
+    import os
+    return max(0, int(os.environ.get("MMSKIN_DP_LAG", "0")))
+
+
 def broadcast_parameters(model, src=0):
     """Make every rank start from rank `src`'s parameters and buffers."""
     # broadcast into detach() views, not `.data`: a detached view shares the parameter's version counter, so caches keyed by it
@@ -128,6 +138,7 @@ class OverlappedGradSync:
             return
         on_gpu = flat.is_cuda
         nstreams = min(len(segs), max_inflight_segments())
+        lag = segment_lag()
         while on_gpu and len(self._streams) < nstreams:
             self._streams.append(torch.cuda.Stream(device=flat.device))
         for i, (off, numel) in enumerate(segs):
@@ -136,6 +147,8 @@ class OverlappedGradSync:
                 s = self._streams[i % nstreams]       # segment i + nstreams queues behind segment i on the same wait stream
                 with torch.cuda.stream(s):
                     plan.wait_grad_segment(i, s)      # s waits for the segment's events only, not for the rest of backward
+                    if lag:                           # ... and, lagged, for a later segment's (segments complete in order)
+                        plan.wait_grad_segment(min(i + lag, len(segs) - 1), s)
                     self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
             else:
                 self._works.append(dist.all_reduce(view, group=self.group, async_op=True))
