@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   constexpr int CPRX = PX / 16, CPRY = PY / 16;
   constexpr int PCX = XB / 1024, PCY = YB / 1024;               // DMA pieces per stage
   constexpr int NXW = G * PCX / 8, NYW = G * PCY / 8, NPW = NXW + NYW;   // pieces per wave and iteration
-  static_assert(WPG == 4 || WPG == 8, "4 or 8 waves per pixel group");
+  static_assert(WPG == 2 || WPG == 4 || WPG == 8, "2, 4 or 8 waves per pixel group");
   static_assert((G * PCX) % 8 == 0 && (G * PCY) % 8 == 0, "pieces must divide over 8 waves");
   static_assert(NIT >= 2 && (NIT - 2) * NPW < 64, "ring depth");
   static_assert((G - 1) * BO * BK * 4 <= NIT * ITB, "group reduction overlays the ring");
@@ -274,6 +274,8 @@ bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r) {
   else if (Cout % 128 == 0 && Ktot % 128 == 0) { r.wo = 2; r.wk = 2; }
   else if (Cout % 256 == 0) { r.wo = 4; r.wk = 1; }
   else if (Ktot % 256 == 0) { r.wo = 1; r.wk = 4; }
+  else if (Cout % 128 == 0) { r.wo = 2; r.wk = 1; }     // Ktot = 64 x odd (DenseNet's 1x1 bottlenecks): 128 x 64 tiles, four pixel groups
+  else if (Ktot % 128 == 0) { r.wo = 1; r.wk = 2; }
   else return false;
   const int G = 8 / (r.wo * r.wk), step = G * 32;
   const int tiles = (Cout / (64 * r.wo)) * (Ktot / (64 * r.wk));
@@ -421,5 +423,7 @@ int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st) {
   if (r.wo == 2 && r.wk == 4) return deep ? ring_launch_t<2, 4, 4>(a, r.s1, st) : ring_launch_t<2, 4, 3>(a, r.s1, st);
   if (r.wo == 2 && r.wk == 2) return deep ? ring_launch_t<2, 2, 3>(a, r.s1, st) : ring_launch_t<2, 2, 2>(a, r.s1, st);
   if (r.wo == 4 && r.wk == 1) return deep ? ring_launch_t<4, 1, 3>(a, r.s1, st) : ring_launch_t<4, 1, 2>(a, r.s1, st);
-  return deep ? ring_launch_t<1, 4, 3>(a, r.s1, st) : ring_launch_t<1, 4, 2>(a, r.s1, st);
+  if (r.wo == 1 && r.wk == 4) return deep ? ring_launch_t<1, 4, 3>(a, r.s1, st) : ring_launch_t<1, 4, 2>(a, r.s1, st);
+  if (r.wo == 2 && r.wk == 1) return ring_launch_t<2, 1, 2>(a, r.s1, st);     // 48 KB per iteration (four groups): two deep
+  return ring_launch_t<1, 2, 2>(a, r.s1, st);
 }

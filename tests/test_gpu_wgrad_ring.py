@@ -35,6 +35,9 @@ CASES = [
     (2, 128, 15, 13, 128, 3, 2, 1, "3x3 stride 2, odd sizes"),
     (16, 128, 28, 28, 128, 3, 2, 1, "3x3 stride 2 over 6 splits that cross image boundaries"),
     (2, 64, 12, 12, 256, 3, 2, 1, "Cin = 64: nine 64-wide k tiles, one tap each, 256x64 tiles"),
+    (3, 192, 14, 14, 128, 1, 1, 0, "128x64 tiles, FOUR pixel groups of two waves (DenseNet bottleneck: Ktot = 64 x 3), ragged"),
+    (24, 320, 14, 14, 128, 1, 1, 0, "128x64 tiles over several splits"),
+    (3, 128, 14, 14, 64, 1, 1, 0, "64x128 tiles, four groups"),
 ]
 
 
