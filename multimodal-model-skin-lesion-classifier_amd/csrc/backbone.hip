@@ -419,7 +419,8 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
         // (the block's widest tensor) is neither written nor read: 2T + 2t bytes instead of 4T + t, and the normalisation multiplies the
         // fp32 accumulator, not a bf16-rounded copy of it
         FwdFuse f2; f2.mul = coef; f2.bias = coef + C; f2.addend = in; f2.relu = true; f2.mask_out = ws + b.mask_off;
-        PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 0) + (double)u.rows() * C * sizeof(T), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f2));
+        // (class accounting: the recomputed MACs are overhead, not algorithmic work -- the layer's FLOPs were counted with the first pass)
+        PROF(K_CONV_FWD, 0.0, conv_bytes(u.s, sizeof(T), 0) + (double)u.rows() * C * sizeof(T), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f2));
       } else if (i + 1 < nu) {
         PROF(K_BN_FWD, 0.0, 2.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
       } else if (b.ds >= 0) {

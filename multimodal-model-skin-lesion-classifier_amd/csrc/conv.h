@@ -101,7 +101,7 @@ struct WgradArgs {
 
 // ring form of the weight-gradient GEMM (wgrad_ring.hip): tile = 64 wo x 64 wk, 8 waves, 8 / (wo wk) pixel groups per workgroup
 struct WgradRingPlan { int wo, wk, nsplit, mps; bool s1; int gram_tiles; };
-bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r);        // tile shape + split count from the GEMM dimensions alone (slab sizing)
+bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r, bool simple);   // tile shape + split count from the GEMM dimensions (simple: 1x1 / stride 1)
 bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r);              // false: the shape stays on the register-staged kernel of wgrad.hip
 int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st);   // fills a.nsplit / m_per_split / nblk_*; the caller reduces the slabs
 int wgrad_ring_launch_count();

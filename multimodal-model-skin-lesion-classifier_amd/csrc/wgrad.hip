@@ -439,7 +439,8 @@ static size_t slab_bytes(int M, int Cout, int Ktot, int ntaps) {
   wgrad_plan(M, Cout, Ktot, WG<T>::MS, BO, BKK, ns, mps, ntaps);
   if constexpr (sizeof(T) == 2) {   // the ring kernel (wgrad_ring.hip) splits differently
     WgradRingPlan rp;
-    if (wgrad_ring_tile(M, Cout, Ktot, rp) && rp.nsplit > ns) ns = rp.nsplit;
+    for (int simple = 0; simple < 2; ++simple)
+      if (wgrad_ring_tile(M, Cout, Ktot, rp, simple != 0) && rp.nsplit > ns) ns = rp.nsplit;
   }
   return (size_t)(ns + (ns > WG_DIRECT_SPLITS ? WG_GROUPS : 0)) * Cout * Ktot * sizeof(float);
 }

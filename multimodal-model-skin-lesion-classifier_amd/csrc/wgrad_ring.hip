@@ -266,10 +266,15 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
 // ------------------------------------------------------------------------------------------ host
 static int ring_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
-bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r) {
+bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r, bool simple) {
   static const int enabled = ring_env("MMSKIN_WGRAD_RING", 1);
   if (!enabled || Cout % 64 || Ktot % 64) return false;
-  if (Cout % 256 == 0 && Ktot % 128 == 0) { r.wo = 4; r.wk = 2; }
+  // 1x1 / stride 1 layers: 128 x 128 tiles with two pixel groups wherever they fit -- half the slab bytes per workgroup for 4/3 of the
+  // L2 -> LDS fill: l2.c3 56.5 -> 48.6 us, l3.c3 43.7 -> 40.3, l4.c3 41.8 -> 38.6 (profiles/r04_experiments.txt (4)); the gathering
+  // layers (stride-2 1x1, tapped 3x3) lose with it (l4.c2a 97 -> 134 us) and keep the 256 x 128 tile.  MMSKIN_WGRAD_RING_G2=0: off
+  static const int prefer_g2 = ring_env("MMSKIN_WGRAD_RING_G2", 1);
+  if (prefer_g2 && simple && Cout % 128 == 0 && Ktot % 128 == 0) { r.wo = 2; r.wk = 2; }
+  else if (Cout % 256 == 0 && Ktot % 128 == 0) { r.wo = 4; r.wk = 2; }
   else if (Cout % 128 == 0 && Ktot % 256 == 0) { r.wo = 2; r.wk = 4; }
   else if (Cout % 128 == 0 && Ktot % 128 == 0) { r.wo = 2; r.wk = 2; }
   else if (Cout % 256 == 0) { r.wo = 4; r.wk = 1; }
@@ -292,7 +297,7 @@ bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r) {
 
 // ---- dY^T in, in^T in and colsum(in) in one launch (see conv.h)
 bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r) {
-  if (!wgrad_ring_tile(M, Cout, Cin, r)) return false;
+  if (!wgrad_ring_tile(M, Cout, Cin, r, false)) return false;
   const int BO = 64 * r.wo, G = 8 / (r.wo * r.wk), step = G * 32;
   if (Cin % 8 || (uint64_t)M * Cout * 2 >= 0xE0000000ull) return false;
   r.gram_tiles = ceil_div(Cin, BO);
@@ -377,9 +382,10 @@ bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r) {
   if (a.C % 8 || a.Cpitch % 8) return false;
   // 32-bit byte offsets, out-of-range marker above every tensor
   if ((uint64_t)a.M * a.Cout * 2 >= 0xE0000000ull || (uint64_t)a.N * a.IH * a.IW * a.Cpitch * 2 >= 0xE0000000ull) return false;
-  if (!wgrad_ring_tile(a.M, a.Cout, a.Ktot, r)) return false;
+  const bool s1 = a.simple1x1 && a.Cpitch == a.C;
+  if (!wgrad_ring_tile(a.M, a.Cout, a.Ktot, r, s1)) return false;
   const int step = (8 / (r.wo * r.wk)) * 32;
-  r.s1 = a.simple1x1 && a.Cpitch == a.C;
+  r.s1 = s1;
   if (!r.s1 && ((a.OW + step) * a.OW >= 65536 || (a.OH + step) * a.OH >= 65536)) return false;   // reciprocal pixel stepping
   return true;
 }
