@@ -598,7 +598,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
   // issued before any of them is consumed, so EG*3 16-byte loads are in flight per lane instead of one
   // dependent load->store chain per row (the fused epilogue was running at ~3 TB/s that way).
   constexpr int NR = BM / ROWS_PER_PASS;
-  constexpr int EG_MAX = EPI == 6 ? 2 : 4;   // profile 6 holds 32 B of fp32 residual per row in flight: two rows keep it at the main loop's register count
+#ifndef MMSKIN_EPI_ROWS4
+#define MMSKIN_EPI_ROWS4 4
+#endif
+#ifndef MMSKIN_EPI_ROWS7
+#define MMSKIN_EPI_ROWS7 4
+#endif
+  constexpr int EG_MAX = EPI == 6 ? 2 : (EPI == 4 ? MMSKIN_EPI_ROWS4 : (EPI == 7 ? MMSKIN_EPI_ROWS7 : 4));   // profile 6 holds 32 B of fp32 residual per row in flight: two rows keep it at the main loop's register count
   // the pipelined kernel has ONE workgroup per CU and nothing else to overlap its epilogue with, while its 112 - 128 accumulator
   // registers are dead by now: half of a thread's 14 / 16 rows in flight at a time (7 / 8 x up to 3 16-byte loads) instead of 2 / 4
   constexpr int EG = PIPE ? NR / 2 : (NR < EG_MAX ? NR : (NR % EG_MAX == 0 ? EG_MAX : 2));
