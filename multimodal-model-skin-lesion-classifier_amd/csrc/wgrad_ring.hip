@@ -45,7 +45,10 @@ template <int N> __device__ __forceinline__ void ring_wait_vm() {
 }
 
 // S1: 1x1 / stride 1 / no padding -- gathered-input row m IS pixel m (offsets advance by a constant; no pixel stepping)
-template <int WO, int WK, int NIT, bool S1>
+// STAG: the two halves of the workgroup (waves 0-3 / 4-7: one wave of each on every SIMD) run half an iteration apart -- two barriers per
+// iteration, one half issues its DMA pieces and reads its fragments while the other half multiplies.  With every wave behind ONE barrier per
+// 16 MFMAs, both waves of a SIMD read together and then queue on the matrix pipe together: ~55 % of it on the MFMA-bound layers 3 - 4.
+template <int WO, int WK, int NIT, bool S1, bool STAG = false>
 __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   constexpr int BO = 64 * WO, BK = 64 * WK, WPG = WO * WK, G = 8 / WPG;
   constexpr int PX = BO * 2, PY = BK * 2;                       // LDS row pitches (bytes)
@@ -57,6 +60,7 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
   static_assert(WPG == 2 || WPG == 4 || WPG == 8, "2, 4 or 8 waves per pixel group");
   static_assert((G * PCX) % 8 == 0 && (G * PCY) % 8 == 0, "pieces must divide over 8 waves");
   static_assert(NIT >= 2 && (NIT - 2) * NPW < 64, "ring depth");
+  static_assert(!STAG || NIT >= 3, "the late half waits one iteration deeper");
   static_assert((G - 1) * BO * BK * 4 <= NIT * ITB, "group reduction overlays the ring");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -188,8 +192,25 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
 #pragma unroll
   for (int s = 0; s < NIT - 1; ++s) RING_ISSUE(s * ITB);
   int buf_rd = 0, buf_wr = (NIT - 1) * ITB;
-  for (int it = 0; it < nit; ++it) {
+  // STAG timeline (B = barrier; the late half runs one barrier behind):
+  //   early:  B  issue(it+NIT-1) read(it) lgkm0   B  mfma(it)                      B  issue ...
+  //   late:      mfma(it-1)                        B  issue(it+NIT-1) read(it) lgkm0 B  mfma(it) ...
+  // RAW: a half reads iteration j after its own first barrier of j; its own pieces were waited for in front of that barrier, the
+  // OTHER half's in front of the other half's previous barrier -- which for the early half reading j is the late half's first barrier
+  // of j - 1: the late half therefore waits one iteration deeper (NIT - 3 instead of NIT - 2 iterations left in flight).
+  // WAR: reads complete (lgkmcnt(0)) before the second barrier, and a buffer is refilled two or more barriers after that.
+  const bool late = STAG && wid >= 4;
+  if (late) {   // the early half reads iteration 0 behind this barrier: the late half's pieces of it must have landed
     ring_wait_vm<(NIT - 2) * NPW>();
+    asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+  }
+  for (int it = 0; it < nit; ++it) {
+    if constexpr (STAG) {
+      if (late) ring_wait_vm<(NIT - 3) * NPW>(); else ring_wait_vm<(NIT - 2) * NPW>();
+    } else {
+      ring_wait_vm<(NIT - 2) * NPW>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     RING_ISSUE(buf_wr);
     const unsigned char* sb = smem + buf_rd + gg * STG;
@@ -203,6 +224,12 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
     for (int i = 0; i < 4; ++i) {
       const uint2 lo = ring_tr16(sb + ya[0][i]), hi = ring_tr16(sb + ya[1][i]);
       fy[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    if constexpr (STAG) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -218,6 +245,7 @@ __global__ __launch_bounds__(512) void wgrad_ring_kernel(const WgradArgs p) {
     buf_rd = buf_rd + ITB == NIT * ITB ? 0 : buf_rd + ITB;
     buf_wr = buf_wr + ITB == NIT * ITB ? 0 : buf_wr + ITB;
   }
+  if (STAG && !late) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }   // the early half's share of the late half's last barrier
 #undef RING_ISSUE
   // the trailing (all-zero) pieces still land in the ring: drain them before the ring is reused
   ring_wait_vm<0>();
@@ -390,7 +418,7 @@ bool wgrad_ring_plan(const WgradArgs& a, WgradRingPlan& r) {
   return true;
 }
 
-template <int WO, int WK, int NIT>
+template <int WO, int WK, int NIT, bool STAG = false>
 static int ring_launch_t(const WgradArgs& a, bool s1, hipStream_t st) {
   constexpr int G = 8 / (WO * WK), LDS = NIT * G * 32 * (64 * WO + 64 * WK) * 2;
   static_assert(LDS <= 160 * 1024, "ring exceeds the LDS");
@@ -398,16 +426,16 @@ static int ring_launch_t(const WgradArgs& a, bool s1, hipStream_t st) {
   static bool attr_done[2] = {false, false};
   if (s1) {
     if (!attr_done[1]) {
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_kernel<WO, WK, NIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_kernel<WO, WK, NIT, true, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
       attr_done[1] = true;
     }
-    hipLaunchKernelGGL((wgrad_ring_kernel<WO, WK, NIT, true>), dim3(grid), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((wgrad_ring_kernel<WO, WK, NIT, true, STAG>), dim3(grid), dim3(512), LDS, st, a);
   } else {
     if (!attr_done[0]) {
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_kernel<WO, WK, NIT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_ring_kernel<WO, WK, NIT, false, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
       attr_done[0] = true;
     }
-    hipLaunchKernelGGL((wgrad_ring_kernel<WO, WK, NIT, false>), dim3(grid), dim3(512), LDS, st, a);
+    hipLaunchKernelGGL((wgrad_ring_kernel<WO, WK, NIT, false, STAG>), dim3(grid), dim3(512), LDS, st, a);
   }
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
@@ -425,6 +453,11 @@ int wgrad_ring_launch(WgradArgs& a, const WgradRingPlan& r, hipStream_t st) {
   ++g_ring_launches;
   // ring depth: G = 1 tiles move 24 KB per iteration (4 deep = 96 KB), G = 2 tiles 32 - 40 KB (3 deep = 96 - 120 KB)
   static const int deep = ring_env("MMSKIN_WGRAD_RING_DEEP", 1);
+  // MMSKIN_WGRAD_RING_STAG (default 1): the MFMA-bound tiles (layers 2 - 4) with the two wave halves half an iteration apart
+  static const int stag = ring_env("MMSKIN_WGRAD_RING_STAG", 1);
+  if (stag && r.wo == 4 && r.wk == 2) return ring_launch_t<4, 2, 4, true>(a, r.s1, st);
+  if (stag && r.wo == 2 && r.wk == 4) return ring_launch_t<2, 4, 4, true>(a, r.s1, st);
+  if (stag && r.wo == 2 && r.wk == 2) return ring_launch_t<2, 2, 4, true>(a, r.s1, st);
   if (r.wo == 4 && r.wk == 2) return deep ? ring_launch_t<4, 2, 4>(a, r.s1, st) : ring_launch_t<4, 2, 3>(a, r.s1, st);
   if (r.wo == 2 && r.wk == 4) return deep ? ring_launch_t<2, 4, 4>(a, r.s1, st) : ring_launch_t<2, 4, 3>(a, r.s1, st);
   if (r.wo == 2 && r.wk == 2) return deep ? ring_launch_t<2, 2, 3>(a, r.s1, st) : ring_launch_t<2, 2, 2>(a, r.s1, st);
