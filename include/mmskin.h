@@ -207,6 +207,11 @@ int mmskin_metablock_gate_backward(const float* dout, const float* V, const floa
 /* inverted dropout with a counter-based generator; mask[n] bytes (1 keep / 0 drop) */
 int mmskin_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
                            uint64_t offset, void* stream);
+/* dropout on attention probabilities [rows][L] (attention_probs_dropout_prob / nn.MultiheadAttention(dropout=p)): the (row, key) generator
+ * every attention kernel of the library applies or regenerates (fused forward / backward, one-wave-per-row kernels), so the unfused
+ * chain softmax -> dropout -> bmm drops the same probabilities; mask as mmskin_dropout_forward (backward: mmskin_dropout_backward) */
+int mmskin_attn_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, int L, float p, uint64_t seed, uint64_t offset,
+                                void* stream);
 int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
 /* out[M, Na+Nb] = [a | b]; backward splits */
 int mmskin_concat2_forward(const float* a, const float* b, float* out, int M, int Na, int Nb, void* stream);

@@ -70,6 +70,38 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// Attention-PROBABILITY dropout (nn.MultiheadAttention(dropout=p) of the TabTransformer, attention_probs_dropout_prob of BERT / GPT-2,
+// attn_drop of timm blocks): keep / drop of probability (row, key) of one call, the same in every kernel that applies or regenerates it
+// (fused forward, its backward, the unfused softmax-attention kernels).  Counter-based like the dropout op, but cheaper: the 64-bit
+// splitmix finaliser per ELEMENT was 275 of the 586 us of the fused forward on the BERT shape (32 hashes per lane and key tile, two
+// 64-bit multiplies each); here ONE 32-bit hash (three 32-bit multiplies) serves the key PAIR (key >> 1) of a row, 16 bits per element.
+// row = flat (batch * head, query) index, Lh = (L + 1) / 2, thr = round(p * 65536) (drop rate exact to 2^-16; the survivors are scaled
+// by 1 / (1 - p) as before).  k0 / k1 = the two halves of mix64(mix64(seed) ^ offset), computed once per kernel.
+struct AttnDropKey { uint32_t k0, k1, thr; };
+__host__ __device__ __forceinline__ AttnDropKey attn_drop_key(uint64_t seed, uint64_t offset, float drop_p) {
+  const uint64_t k = mix64(mix64(seed) ^ offset);
+  AttnDropKey a;
+  a.k0 = (uint32_t)k; a.k1 = (uint32_t)(k >> 32);
+  a.thr = (uint32_t)(drop_p * 65536.0f + 0.5f);
+  return a;
+}
+// rbase = row * Lh (one 64-bit multiply per ROW, hoisted out of the key loops by the callers that walk a row)
+__device__ __forceinline__ uint64_t attn_row_base(uint64_t row, int Lh) { return row * (uint64_t)Lh; }
+__device__ __forceinline__ uint32_t attn_pair_hash(const AttnDropKey& a, uint64_t rbase, int key) {
+  const uint64_t pair = rbase + (uint64_t)(key >> 1);
+  uint32_t h = ((uint32_t)pair ^ a.k0) * 0x9E3779B1u;
+  h ^= h >> 15;
+  h = (h ^ (uint32_t)(pair >> 32) ^ a.k1) * 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ bool attn_keep_bits(uint32_t pair_hash, int key, uint32_t thr) { return ((pair_hash >> (16 * (key & 1))) & 0xffffu) >= thr; }
+__device__ __forceinline__ bool attn_keep(const AttnDropKey& a, uint64_t rbase, int key) {
+  return attn_keep_bits(attn_pair_hash(a, rbase, key), key, a.thr);
+}
+
 // x * Phi(x) with Phi(-|x|) = erfc(|x| / sqrt 2) / 2 from Abramowitz & Stegun 7.1.26 (|error of erf| <= 1.5e-7, i.e. <= 0.75e-7 |x|
 // on the result: below bf16 AND below the fp32 rounding of an O(1) activation): 1 v_rcp + 1 v_exp + 9 multiply-adds, against the
 // ~40-instruction erff() whose cost in a GEMM epilogue was a quarter of the launch (fc1 of BEiT-large: 377 us -> see r02_experiments (10)).

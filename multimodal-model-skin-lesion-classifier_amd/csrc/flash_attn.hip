@@ -41,12 +41,6 @@ struct FlashArgs {
   int ablate;   // -DMMSKIN_ABLATE builds only (scripts/flash_ablate.py): bit0 K / V global loads after tile 0, bit1 softmax VALU work, bit2 MFMAs, bit3 K / V LDS stores
 };
 
-__device__ __forceinline__ uint64_t fa_mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __device__ __forceinline__ uint2 lds_tr16_b64(const unsigned char* p) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   return __builtin_bit_cast(uint2, v);
@@ -60,7 +54,9 @@ __device__ __forceinline__ uint4 load8_bf16(const float* p) {
 }
 __device__ __forceinline__ uint4 load8_bf16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int D, int NB, typename IO>   // NB = LDS buffers for the K / V tiles (1: two barriers per key tile; 2: one); IO = tensor dtype
+// NB = LDS buffers for the K / V tiles (1: two barriers per key tile; 2: one); IO = tensor dtype; DROP: attention-probability dropout compiled in
+// (as a run-time test the generator's code kept 24 - 28 more VGPRs live in the launches that never drop: 3 -> 2 waves per SIMD at Dh = 64)
+template <int D, int NB, typename IO, bool DROP>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   constexpr int BQ = 64, BK = 64;
   constexpr int PITCH = D * 2 + 16;          // bytes per K / V row in LDS
@@ -136,8 +132,14 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   };
 
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint64_t seed_mix = fa_mix64(p.seed);
+  const AttnDropKey dk = attn_drop_key(p.seed, p.offset, p.drop_p);
+  const int Lh = (L + 1) >> 1;
   const int q_lane0 = q0 + wid * 16 + 4 * g;      // first of this lane's 4 query rows
+  uint64_t drb[4] = {0, 0, 0, 0};
+  if constexpr (DROP) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) drb[r] = attn_row_base((uint64_t)bh * L + (uint64_t)(q_lane0 + r), Lh);
+  }
   const int tq = l15 >> 2, tp = l15 & 3;          // transposing-read roles inside a 16-lane group
 
   // ONE barrier per key tile: tile t+1 is fetched into registers while tile t is multiplied and lands in the OTHER LDS buffer
@@ -217,10 +219,8 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
       for (int r = 0; r < 4; ++r) {
         float pv = ok[n][r] ? __expf(s[n][r] - m_run[r]) : 0.f;
         rs[r] += pv;
-        if (p.drop_p > 0.f && ok[n][r]) {
-          const uint64_t gi = (((uint64_t)bh * L + (uint64_t)(q_lane0 + r)) * L) + (uint64_t)kj;
-          const uint64_t hsh = fa_mix64(seed_mix ^ (p.offset + gi));
-          pv = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? pv * inv_keep : 0.f;
+        if constexpr (DROP) {
+          if (ok[n][r]) pv = attn_keep(dk, drb[r], kj) ? pv * inv_keep : 0.f;
         }
         *reinterpret_cast<uint16_t*>(Ps + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(pv);
       }
@@ -275,14 +275,230 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs p) {
   }
 }
 
+// ---- round 4: 32 query rows per wave, no P round trip through LDS (Dh = 64)
+// The kernel above gives a wave 16 query rows: every wave re-reads the whole 64-key K and V tiles for 16 MFMAs, P goes accumulator -> bf16 ->
+// LDS -> operand, and every row statistic is a 4-step xor-shuffle (ablation, profiles/r02_experiments.txt (14): 307 of 822 us remain with
+// loads, softmax, MFMAs and LDS stores all removed).  Here:
+//   * S^T = K Q^T on v_mfma_f32_32x32x16_bf16 with the operands SWAPPED (A = K rows, B = Q^T): the accumulator holds a QUERY per lane column
+//     and 16 of a 32-key tile's scores in its registers (the other 16 in lane + 32) -- max / sum over keys are in-register loops plus ONE
+//     xor-32 shuffle, bias / mask / dropout index one (query, key) per register
+//   * O^T += V^T P^T takes the exponentiated accumulator ITSELF as the B operand (registers 8s..8s+7 -> bf16 are the fragment of k-step s; the
+//     matching k order of the V^T fragment is keys 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}: two transposing reads) -- no LDS write,
+//     no barrier, no second layout
+//   * a workgroup is 128 query rows (4 waves x 32): the K / V tiles are fetched and staged once per 128 queries instead of per 64, and
+//     each fragment read feeds twice the MFMA work
+// Same staging (registers -> bf16 -> LDS, pitch D*2 + 16), same dropout generator, masks, strides and LSE as the kernel above.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <typename IO, bool DROP>
+__global__ __launch_bounds__(256) void flash_fwd2_kernel(const FlashArgs p) {
+  constexpr int D = 64, BQ = 128, BK = 64;
+  constexpr int PITCH = D * 2 + 16;
+  constexpr int CPT = BK * (D / 8) / 256;    // 8-element chunks per thread per tile (K and V each) = 2
+  constexpr int KV_BYTES = 2 * BK * PITCH;
+  constexpr int MAXL = 1024;                 // key-mask row kept in LDS (log2 domain); longer sequences take the kernel above
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BYTES + MAXL * 4];
+  float* mask_s = reinterpret_cast<float*>(smem + 2 * KV_BYTES);
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int lin0 = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int lin = p.xcd ? xcd_remap(lin0, (int)(gridDim.x * gridDim.y)) : lin0;
+  const int bh = lin / (int)gridDim.x, b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (lin - bh * (int)gridDim.x) * BQ;
+  const int L = p.L;
+  const int qi = q0 + wid * 32 + r;          // this lane's query (both lane halves hold the same one)
+  const bool q_ok = qi < L;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float sc2 = p.scale * LOG2E;         // scores live in the log2 domain: exp2 needs no multiply per element
+
+  // the key mask of this batch row, once, in the log2 domain; keys past L get the most negative finite value's stand-in (never used: invalid)
+  for (int k = tid; k < ((L + BK - 1) / BK) * BK; k += 256) mask_s[k] = (p.mask_add && k < L) ? fmaxf(p.mask_add[(int64_t)b * L + k] * LOG2E, -3.4028235e38f) : 0.f;   // HF's finfo.min stays finite: a fully masked row is the uniform average, as torch gives it
+
+  // Q^T as the B operand: lane (r, hh) holds Q[query r][d = 16 ks + 8 hh .. +7]
+  uint4 qf[4];
+  {
+    const IO* qp = reinterpret_cast<const IO*>(p.q) + b * p.q_sb + h * p.q_sh + (int64_t)(q_ok ? qi : L - 1) * p.q_sl;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = load8_bf16(qp + 16 * ks + 8 * hh);
+  }
+  float m_run = -3.4028235e38f, l_run = 0.f;     // running max in the log2 domain
+  f32x16_t oacc[2];      // O^T: rows d = 32 dt + (i & 3) + 8 (i >> 2) + 4 hh in register i, column = query r
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+
+  const IO* kbase = reinterpret_cast<const IO*>(p.k) + b * p.k_sb + h * p.k_sh;
+  const IO* vbase = reinterpret_cast<const IO*>(p.v) + b * p.v_sb + h * p.v_sh;
+  const int nt_all = (L + BK - 1) / BK;
+  const int nt = p.causal ? min(nt_all, (min(q0 + BQ, L) + BK - 1) / BK) : nt_all;
+
+  uint4 kr[CPT], vr[CPT];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + 256 * i, key = c >> 3, dc = c & 7;
+      const int kj = t * BK + key;
+      if (kj < L) {
+        kr[i] = load8_bf16(kbase + (int64_t)kj * p.k_sl + dc * 8);
+        vr[i] = load8_bf16(vbase + (int64_t)kj * p.v_sl + dc * 8);
+      } else {
+        kr[i] = make_uint4(0u, 0u, 0u, 0u);
+        vr[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* Kd = smem + buf * KV_BYTES;
+    unsigned char* Vd = Kd + BK * PITCH;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int c = tid + 256 * i, key = c >> 3, dc = c & 7;
+      *reinterpret_cast<uint4*>(Kd + key * PITCH + dc * 16) = kr[i];
+      *reinterpret_cast<uint4*>(Vd + key * PITCH + dc * 16) = vr[i];
+    }
+  };
+
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const AttnDropKey dk = attn_drop_key(p.seed, p.offset, p.drop_p);
+  const int Lh = (L + 1) >> 1;
+  const uint64_t drow = attn_row_base((uint64_t)bh * L + (uint64_t)qi, Lh);
+  const int l15 = lane & 15, tq = l15 >> 2, tp = l15 & 3, G = lane >> 4;   // transposing-read roles: group G = 16 d columns 16 (G & 1).., lane half G >> 1
+
+  if (nt > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* Ks = smem + (t & 1) * KV_BYTES;
+    const unsigned char* Vs = Ks + BK * PITCH;
+    if (t + 1 < nt) load_tile(t + 1);
+
+    // ---- S^T = K Q^T: two 32-key tiles, 4 k-steps of 16 each
+    f32x16_t s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (32 * kt + r) * PITCH + (16 * ks + 8 * hh) * 2);
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[ks]), s[kt], 0, 0, 0);
+      }
+    }
+    // ---- scale + key mask (LDS, four consecutive keys per read), running max: in-lane over 32 scores + one shuffle across the lane halves.
+    // A tile that lies wholly inside the sequence of a non-causal launch needs no per-element validity (lanes whose query is past L
+    // compute a row nobody stores).
+    const bool edge = p.causal || (t + 1) * BK > L;
+    float mx = -3.4028235e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask_s + t * BK + 32 * kt + 8 * gq + 4 * hh);
+        const float mv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * gq + e;
+          float x = s[kt][i] * sc2 + mv[e];
+          if (edge) {
+            const int kj = t * BK + 32 * kt + 8 * gq + 4 * hh + e;
+            if (!(kj < L && !(p.causal && kj > qi))) x = -INFINITY;       // exp2 -> 0; the max ignores it
+          }
+          s[kt][i] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, -3.4028235e38f);                                         // a row with no valid key so far: finite, so that exp2(-inf - m) = 0 below
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+    uint4 pf[2][2];     // P^T fragments: [key tile][k-step]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float pv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][i] - m_run);
+        rs += e;
+        pv[i] = e;
+      }
+      if constexpr (DROP) {   // a lane's registers are quads of consecutive keys (first key a multiple of 4): two pair hashes per quad
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int kj0 = t * BK + 32 * kt + 8 * gq + 4 * hh;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t hsh = attn_pair_hash(dk, drow, kj0 + 2 * pr);
+            pv[4 * gq + 2 * pr] = attn_keep_bits(hsh, 0, dk.thr) ? pv[4 * gq + 2 * pr] * inv_keep : 0.f;
+            pv[4 * gq + 2 * pr + 1] = attn_keep_bits(hsh, 1, dk.thr) ? pv[4 * gq + 2 * pr + 1] * inv_keep : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+        pf[kt][sk] = make_uint4(pack_bf16(pv[8 * sk], pv[8 * sk + 1]), pack_bf16(pv[8 * sk + 2], pv[8 * sk + 3]),
+                                pack_bf16(pv[8 * sk + 4], pv[8 * sk + 5]), pack_bf16(pv[8 * sk + 6], pv[8 * sk + 7]));
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+    // ---- O^T += V^T P^T: A = V^T fragment (d = 32 dt + lane & 31; keys 16 sk + 4 hh + {0..3}, 16 sk + 8 + 4 hh + {0..3} of the 32-key tile)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        const int k0 = 32 * kt + 16 * sk + 4 * (G >> 1);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int colb = (32 * dt + 16 * (G & 1) + 4 * tp) * 2;
+          const uint2 lo = lds_tr16_b64(Vs + (k0 + tq) * PITCH + colb);
+          const uint2 hi = lds_tr16_b64(Vs + (k0 + 8 + tq) * PITCH + colb);
+          const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[kt][sk]), oacc[dt], 0, 0, 0);
+        }
+      }
+    if (t + 1 < nt) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- O / l, LSE (natural log): lane holds O[qi][32 dt + 8 (i >> 2) + 4 hh + (i & 3)]: four consecutive d per register quad
+  if (!q_ok) return;
+  IO* orow = reinterpret_cast<IO*>(p.o) + b * p.o_sb + h * p.o_sh + (int64_t)qi * p.o_sl;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      IO* dst = orow + 32 * dt + 8 * gq + 4 * hh;
+      const float a0 = oacc[dt][4 * gq] * inv, a1 = oacc[dt][4 * gq + 1] * inv, a2 = oacc[dt][4 * gq + 2] * inv, a3 = oacc[dt][4 * gq + 3] * inv;
+      if constexpr (sizeof(IO) == 4) *reinterpret_cast<float4*>(dst) = make_float4(a0, a1, a2, a3);
+      else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(a0, a1), pack_bf16(a2, a3));
+    }
+  if (p.lse && hh == 0) p.lse[(int64_t)bh * L + qi] = m_run * 0.6931471805599453f + __logf(fmaxf(l_run, 1e-38f));
+}
+
 }  // namespace
 
 template <typename IO>
 static int flash_launch(FlashArgs& a, int Dh, hipStream_t st) {
+  static const int v2 = [] { const char* e = getenv("MMSKIN_FLASH_V2"); return e ? atoi(e) : 1; }();
+  if (v2 && Dh == 64 && !a.bias && a.L <= 1024) {   // 128 query rows per workgroup, in-register softmax (flash_fwd2_kernel); a score bias [H][L][L]
+                                                     // is read per (query, key): with a query per lane its rows are L floats apart -- the kernel above reads it along keys
+    if (a.drop_p > 0.f) hipLaunchKernelGGL((flash_fwd2_kernel<IO, true>), dim3(ceil_div(a.L, 128), a.B * a.H), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((flash_fwd2_kernel<IO, false>), dim3(ceil_div(a.L, 128), a.B * a.H), dim3(256), 0, st, a);
+    HIP_CHECK_RET(hipGetLastError());
+    return MMSKIN_OK;
+  }
   const dim3 grid(ceil_div(a.L, 64), a.B * a.H);
   static const int nb = [] { const char* e = getenv("MMSKIN_FLASH_BUFFERS"); return e ? atoi(e) : 2; }();
-  if (Dh == 32) { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<32, 1, IO>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<32, 2, IO>), grid, dim3(256), 0, st, a); }
-  else { if (nb == 1) hipLaunchKernelGGL((flash_fwd_kernel<64, 1, IO>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((flash_fwd_kernel<64, 2, IO>), grid, dim3(256), 0, st, a); }
+#define FA_GO(DV, NBV) do { if (a.drop_p > 0.f) hipLaunchKernelGGL((flash_fwd_kernel<DV, NBV, IO, true>), grid, dim3(256), 0, st, a); \
+                             else hipLaunchKernelGGL((flash_fwd_kernel<DV, NBV, IO, false>), grid, dim3(256), 0, st, a); } while (0)
+  if (Dh == 32) { if (nb == 1) FA_GO(32, 1); else FA_GO(32, 2); }
+  else { if (nb == 1) FA_GO(64, 1); else FA_GO(64, 2); }
+#undef FA_GO
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -44,12 +44,6 @@ struct FlashBwdArgs {
   uint64_t seed, offset;
 };
 
-__device__ __forceinline__ uint64_t fb_mix64(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __device__ __forceinline__ uint2 fb_tr16_b64(const unsigned char* p) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   return __builtin_bit_cast(uint2, v);
@@ -138,7 +132,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdArgs p)
     }
   };
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint64_t seed_mix = fb_mix64(p.seed);
+  const AttnDropKey dk = attn_drop_key(p.seed, p.offset, p.drop_p);
+  const int Lh = (L + 1) >> 1;
   const int tq = l15 >> 2, tp = l15 & 3;
 
   if (nt > 0) { load_tile(0); store_tile(0); }
@@ -177,11 +172,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashBwdArgs p)
         const float x = s[r] * p.scale + madd[n] + badd[n][r];
         const float pr = valid ? __expf(x - lse_r[r]) : 0.f;
         float zs = 1.f;
-        if (p.drop_p > 0.f && valid) {
-          const uint64_t gi = (((uint64_t)bh * L + (uint64_t)qi) * L) + (uint64_t)kj;
-          const uint64_t hsh = fb_mix64(seed_mix ^ (p.offset + gi));
-          zs = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? inv_keep : 0.f;
-        }
+        if (p.drop_p > 0.f && valid) zs = attn_keep(dk, attn_row_base((uint64_t)bh * L + (uint64_t)qi, Lh), kj) ? inv_keep : 0.f;
         const float ds = pr * (dp[r] * zs - dl_r[r]);
         if (p.ds_out && valid) p.ds_out[(((int64_t)bh * L + qi) * L) + kj] = ds;
         *reinterpret_cast<uint16_t*>(Ps + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(ds * p.scale);
@@ -265,7 +256,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashBwdArgs p
     }
   };
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const uint64_t seed_mix = fb_mix64(p.seed);
+  const AttnDropKey dk = attn_drop_key(p.seed, p.offset, p.drop_p);
+  const int Lh = (L + 1) >> 1;
   const int tq = l15 >> 2, tp = l15 & 3;
 
   if (t_first < nt) { load_tile(t_first); store_tile(t_first & 1); }
@@ -305,11 +297,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashBwdArgs p
         const float x = s[r] * p.scale + madd_r[r] + badd[n][r];
         const float pr = valid ? __expf(x - lse_c[n]) : 0.f;
         float zs = 1.f;
-        if (p.drop_p > 0.f && valid) {
-          const uint64_t gi = (((uint64_t)bh * L + (uint64_t)qi) * L) + (uint64_t)kj;
-          const uint64_t hsh = fb_mix64(seed_mix ^ (p.offset + gi));
-          zs = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? inv_keep : 0.f;
-        }
+        if (p.drop_p > 0.f && valid) zs = attn_keep(dk, attn_row_base((uint64_t)bh * L + (uint64_t)qi, Lh), kj) ? inv_keep : 0.f;
         const float ds = pr * (dp[r] * zs - dl_c[n]);
         *reinterpret_cast<uint16_t*>(Pt + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(pr * zs);
         *reinterpret_cast<uint16_t*>(St + (4 * g + r) * PPITCH + (16 * n + l15) * 2) = (uint16_t)f32_to_bf16_bits(ds * p.scale);

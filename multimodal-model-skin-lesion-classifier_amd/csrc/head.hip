@@ -765,6 +765,20 @@ __global__ void dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, int6
     y[i] = keep ? x[i] * scale : 0.f;
   }
 }
+// dropout on attention PROBABILITIES laid out [rows][L] (the unfused softmax-attention chain): the (row, key) generator of common.h, so the
+// unfused chain drops exactly what the fused kernels drop
+__global__ void attn_dropout_fwd_kernel(const float* x, float* y, uint8_t* mask, int64_t n, int L, float p, uint64_t seed, uint64_t offset) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  const AttnDropKey dk = attn_drop_key(seed, offset, p);
+  const int Lh = (L + 1) >> 1;
+  EW_LOOP(n) {
+    const uint64_t row = (uint64_t)i / (uint64_t)L;
+    const int key = (int)((uint64_t)i - row * (uint64_t)L);
+    const uint8_t keep = attn_keep(dk, attn_row_base(row, Lh), key) ? 1 : 0;
+    mask[i] = keep;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
 __global__ void dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p) {
   const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
   EW_LOOP(n) dx[i] = mask[i] ? dy[i] * scale : 0.f;
@@ -789,10 +803,7 @@ __global__ void concat2_bwd_kernel(const float* dout, float* da, float* db, int 
 // one workgroup per (b, h); L*L scores in LDS; one wave per score row for the softmax.  Training-mode
 // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) inside the TabTransformer's
 // encoder layers) uses the same counter-based generator as the dropout op: element gi of call `offset`.
-__device__ __forceinline__ bool attn_keep(uint64_t seed, uint64_t offset, int64_t gi, float drop_p) {
-  uint64_t h = mix64(mix64(seed) ^ (offset + (uint64_t)gi));
-  return (float)(h >> 40) * (1.0f / 16777216.0f) >= drop_p;
-}
+// (the generator: attn_keep / AttnDropKey in common.h, shared with the fused kernels of flash_attn*.hip)
 __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                             const float* __restrict__ v, float* __restrict__ o,
                                                             float* __restrict__ p, int L, int Dh, float drop_p,
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
       float pv = sc[i * L + j] * inv;
       const int64_t gi = (int64_t)blockIdx.x * L * L + i * L + j;
       p[gi] = pv;   // the pure softmax is what backward needs; the dropout mask is recomputed there
-      if (drop_p > 0.f) pv = attn_keep(seed, offset, gi, drop_p) ? pv * (1.f / (1.f - drop_p)) : 0.f;
+      if (drop_p > 0.f) pv = attn_keep(attn_drop_key(seed, offset, drop_p), attn_row_base((uint64_t)blockIdx.x * L + i, (L + 1) >> 1), j) ? pv * (1.f / (1.f - drop_p)) : 0.f;
       sc[i * L + j] = pv;
     }
   }
@@ -843,8 +854,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const float* __restr
   const float* pp = p + pbase;
   const float scale = 1.0f / sqrtf((float)Dh);
   const float dscale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (int idx = threadIdx.x; idx < L * L; idx += 256)   // dropout factor of every probability
-    ds[idx] = (drop_p > 0.f && !attn_keep(seed, offset, pbase + idx, drop_p)) ? 0.f : dscale;
+  for (int idx = threadIdx.x; idx < L * L; idx += 256) {   // dropout factor of every probability
+    const int i = idx / L, j = idx - i * L;
+    ds[idx] = (drop_p > 0.f && !attn_keep(attn_drop_key(seed, offset, drop_p), attn_row_base((uint64_t)blockIdx.x * L + i, (L + 1) >> 1), j)) ? 0.f : dscale;
+  }
   __syncthreads();
   for (int idx = threadIdx.x; idx < L * Dh; idx += 256) {  // dV = P'^T dO,  P' = P * factor
     int j = idx / Dh, d = idx - j * Dh;
@@ -960,7 +973,7 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
     ROWS_STEP(jt, jx);
   }
   const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const int64_t gi0 = ((int64_t)head * L + row) * L;
+  const AttnDropKey dkey = attn_drop_key(p.seed, p.offset, p.drop_p);
   float ov[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) ov[d] = 0.f;
@@ -971,10 +984,7 @@ __global__ __launch_bounds__(256) void attention_rows_fwd_kernel(const float* __
     const float* __restrict__ vr = vb + jt * p.qs_l;
     float e = expf(Ss[j * 64] - mx);
     sum += e;                                                // the softmax denominator counts dropped probabilities too
-    if (p.drop_p > 0.f) {
-      const uint64_t hsh = mix64(mix64(p.seed) ^ (p.offset + (uint64_t)(gi0 + j)));
-      e = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? e * keep_scale : 0.f;
-    }
+    if (p.drop_p > 0.f) e = attn_keep(dkey, attn_row_base((uint64_t)head * L + row, (L + 1) >> 1), j) ? e * keep_scale : 0.f;
 #pragma unroll
     for (int d = 0; d < DH; ++d) ov[d] = fmaf(e, vr[d], ov[d]);
     ROWS_STEP(jt, jx);
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
     }
     const float lse = glse[(int64_t)head * L + row];
     const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-    const int64_t gi0 = ((int64_t)head * L + row) * L;
+    const AttnDropKey dkey = attn_drop_key(p.seed, p.offset, p.drop_p);
     int jt = 0, jx = 0;
 #pragma unroll 1
     for (int j = 0; j < L; ++j) {
@@ -1044,10 +1054,7 @@ __global__ __launch_bounds__(256) void attention_rows_bwd_kernel(const float* __
       for (int d = 0; d < DH; ++d) { a = fmaf(qv[d], kr[d], a); c = fmaf(gvv[d], vr[d], c); }
       const float pj = expf(a - lse);
       float f = 1.f;
-      if (p.drop_p > 0.f) {
-        const uint64_t hsh = mix64(mix64(p.seed) ^ (p.offset + (uint64_t)(gi0 + j)));
-        f = ((float)(hsh >> 40) * (1.0f / 16777216.0f) >= p.drop_p) ? keep_scale : 0.f;
-      }
+      if (p.drop_p > 0.f) f = attn_keep(dkey, attn_row_base((uint64_t)head * L + row, (L + 1) >> 1), j) ? keep_scale : 0.f;
       const float ds = pj * (f * c - delta) * p.scale;
       if (act) { dSs[lane * LP + j] = ds; Pps[lane * LP + j] = pj * f; }
 #pragma unroll
@@ -1776,6 +1783,11 @@ int mmskin_metablock_gate_backward(const float* dout, const float* V, const floa
 int mmskin_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed, uint64_t offset,
                            void* stream) {
   EW_LAUNCH(dropout_fwd_kernel, n, x, y, mask, n, p, seed, offset);
+}
+int mmskin_attn_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, int L, float p, uint64_t seed, uint64_t offset,
+                                void* stream) {
+  ARG_CHECK(L > 0 && n % L == 0, "attn_dropout_forward: n=%lld is not rows x L=%d", (long long)n, L);
+  EW_LAUNCH(attn_dropout_fwd_kernel, n, x, y, mask, n, L, p, seed, offset);
 }
 int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
   EW_LAUNCH(dropout_bwd_kernel, n, dy, mask, dx, n, p);

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mmskin_metablock_gate_forward": (_i, [_P] * 4 + [_i64, _P]),
     "mmskin_metablock_gate_backward": (_i, [_P] * 7 + [_i64, _P]),
     "mmskin_dropout_forward": (_i, [_P] * 3 + [_i64, _f, _u64, _u64, _P]),
+    "mmskin_attn_dropout_forward": (_i, [_P] * 3 + [_i64, _i, _f, _u64, _u64, _P]),
     "mmskin_dropout_backward": (_i, [_P] * 3 + [_i64, _f, _P]),
     "mmskin_concat2_forward": (_i, [_P] * 3 + [_i] * 3 + [_P]),
     "mmskin_concat2_backward": (_i, [_P] * 3 + [_i] * 3 + [_P]),

@@ -620,7 +620,7 @@ class LongAttentionFn(torch.autograd.Function):
         if drop_p > 0.0:
             pd = torch.empty_like(probs)
             dmask = torch.empty(probs.shape, device=q.device, dtype=torch.uint8)
-            call("mmskin_dropout_forward", ptr(probs), ptr(pd), ptr(dmask), probs.numel(), float(drop_p), int(seed), int(offset), stream())
+            call("mmskin_attn_dropout_forward", ptr(probs), ptr(pd), ptr(dmask), probs.numel(), L, float(drop_p), int(seed), int(offset), stream())
         o = torch.empty_like(q)
         _bmm(pd, v, o, BH, L, Dh, L, L, 1, L * L, 1, Dh, L * Dh, Dh, L * Dh)          # o[i][d] = sum_j pd[i][j] v[j][d]
         ctx.save_for_backward(q, k, v, probs, pd if drop_p > 0.0 else None, dmask)
