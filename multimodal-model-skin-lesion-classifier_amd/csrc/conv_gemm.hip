@@ -862,7 +862,10 @@ static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, Pi
     if (cost < best) { best = cost; best_tiles = tiles; out->bm = cand[c][0]; out->step = cand[c][1]; }
   }
   if (best >= 1e30) return false;
-  return force || (ksum / rsum >= mink && best_tiles >= mintiles);
+  // Linear GEMMs ({M, 1, 1, K, N}: no gather, one tap) already pay at K = 768 (BERT-base qkv / fc1 / output.dense: config 5 50.7 -> 50.3 ms);
+  // the ResNet convolutions do not below 1024 (profiles/r04_experiments.txt (0))
+  const double mink_eff = (a.IH == 1 && a.IW == 1 && a.ncls == 1 && mink == 1024) ? 768 : mink;
+  return force || (ksum / rsum >= mink_eff && best_tiles >= mintiles);
 }
 
 template <typename T>
