@@ -139,6 +139,16 @@ int64_t mmskin_wgrad3_ring_launches(void);   /* ... of the all-taps 3x3 ring ker
 int64_t mmskin_abn_workspace_bytes(int N, int Cw, int C4, int H, int W);
 int mmskin_abn_backward(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
                         int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream);
+/* ... with the Gram matrix y^T y and colsum(y) taken by their own launch first and g^T y alone afterwards: the order of the two-pass
+ * forward, whose first pass computes them for the statistics below and keeps them for this backward */
+int mmskin_abn_backward_kept_gram(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N,
+                                  int Cw, int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream);
+/* Batch statistics of x = conv1x1(y, w) without x: stat_sum[o] = sum x[.,o] = sum_k w[o][k] colsum(y)[k], stat_sq[o] = sum x[.,o]^2 =
+ * w_o^T (y^T y) w_o (bf16 operands, fp32 Gram matrix from the ring weight-gradient kernel, double-precision contraction).  The first
+ * pass of the two-pass BatchNorm forward of Bottleneck.conv3 + bn3 (train-mode nn.BatchNorm2d statistics, train_pad_20.py:102);
+ * workspace: mmskin_abn_workspace_bytes. */
+int mmskin_conv1x1_gram_stats(const float* y, const float* w, int N, int Cw, int C4, int H, int W, float* stat_sum, float* stat_sq,
+                              void* workspace, void* stream);
 /* training-mode BatchNorm2d + optional ReLU on NCHW fp32 tensors (batch statistics) */
 int64_t mmskin_batchnorm_workspace_bytes(int N, int C, int H, int W);
 int mmskin_batchnorm_forward(const float* x, const float* gamma, const float* beta, float* running_mean,

@@ -68,10 +68,9 @@ int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, 
 
 // dW[o][k] = cA[o] S[o][k] + cB[o] sum_k' W[o][k'] Gm[k'][k] + cC[o] colsum[k];  S = [g^T y ; y^T y] as [C4 + gram rows][Cw]
 // grid = C4 blocks, Cw threads (Cw <= 256)
-__global__ void abn_wgrad_finalize_kernel(const float* __restrict__ S, const float* __restrict__ colsum, const float* __restrict__ W,
-                                          const float* __restrict__ coef, int C4, int Cw, float* __restrict__ dW) {
+__global__ void abn_wgrad_finalize_kernel(const float* __restrict__ S, const float* __restrict__ Gm, const float* __restrict__ colsum,
+                                          const float* __restrict__ W, const float* __restrict__ coef, int C4, int Cw, float* __restrict__ dW) {
   const int o = blockIdx.x, k = threadIdx.x;
-  const float* Gm = S + (size_t)C4 * Cw;
   float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // Cw % 4 == 0
   const float* wr = W + (size_t)o * Cw;
   for (int k2 = 0; k2 < Cw; k2 += 4) {
@@ -84,9 +83,10 @@ __global__ void abn_wgrad_finalize_kernel(const float* __restrict__ S, const flo
   dW[(size_t)o * Cw + k] = coef[o] * S[(size_t)o * Cw + k] + coef[C4 + o] * t + coef[2 * C4 + o] * colsum[k];
 }
 
-int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st) {
+int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st,
+                       const float* gram) {
   ARG_CHECK(Cw <= 256, "abn_wgrad_finalize: Cw=%d", Cw);
-  hipLaunchKernelGGL(abn_wgrad_finalize_kernel, dim3(C4), dim3(Cw), 0, st, S, colsum, W, coef, C4, Cw, dW);
+  hipLaunchKernelGGL(abn_wgrad_finalize_kernel, dim3(C4), dim3(Cw), 0, st, S, gram ? gram : S + (size_t)C4 * Cw, colsum, W, coef, C4, Cw, dW);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
@@ -103,6 +103,39 @@ __global__ __launch_bounds__(64) void abn_sgx_kernel(const float* __restrict__ S
 }
 int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStream_t st) {
   hipLaunchKernelGGL(abn_sgx_kernel, dim3(C4), dim3(64), 0, st, S, W, Cw, sgx);
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+
+// ---- forward: the BatchNorm statistics of x = y W^T from the Gram matrix and the column sums of y (one pass over y, the block's
+// narrowest tensor, instead of a statistics-only pass of the convolution):
+//     sum_m x[m][o] = sum_k W[o][k] colsum[k]            sum_m x[m][o]^2 = w_o^T (y^T y) w_o
+// W as multiplied (bf16-rounded); sums in double, stored as the one-row fp32 statistics table bn_finalize reads.  grid = C4 blocks, Cw threads.
+__global__ __launch_bounds__(256) void gram_stats_kernel(const float* __restrict__ Gm, const float* __restrict__ colsum, const float* __restrict__ W,
+                                                         int Cw, float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+  __shared__ float wrow[256];
+  __shared__ double red[2][256];
+  const int o = blockIdx.x, k = threadIdx.x;
+  const float wk = abn_wb(W[(size_t)o * Cw + k]);
+  wrow[k] = wk;
+  __syncthreads();
+  double t0 = 0.0, t1 = 0.0;
+  for (int k2 = 0; k2 < Cw; k2 += 2) {
+    t0 += (double)wrow[k2] * (double)Gm[(size_t)k2 * Cw + k];
+    t1 += (double)wrow[k2 + 1] * (double)Gm[(size_t)(k2 + 1) * Cw + k];
+  }
+  red[0][k] = (double)wk * (double)colsum[k];
+  red[1][k] = (double)wk * (t0 + t1);
+  __syncthreads();
+  for (int s = Cw >> 1; s > 0; s >>= 1) {
+    if (k < s) { red[0][k] += red[0][k + s]; red[1][k] += red[1][k + s]; }
+    __syncthreads();
+  }
+  if (k == 0) { stat_sum[o] = (float)red[0][0]; stat_sq[o] = (float)red[1][0]; }
+}
+int gram_stats(const float* gram, const float* colsum, const float* W, int C4, int Cw, float* stat_sum, float* stat_sq, hipStream_t st) {
+  ARG_CHECK(Cw == 64 || Cw == 128 || Cw == 256, "gram_stats: Cw=%d", Cw);
+  hipLaunchKernelGGL(gram_stats_kernel, dim3(C4), dim3(Cw), 0, st, gram, colsum, W, Cw, stat_sum, stat_sq);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -21,6 +21,7 @@ struct Unit {  // conv + batch-norm
   size_t y_off;                  // post-activation output (bytes); for the last unit of a block = block output
   size_t coef_off;               // floats: scale, shift, mean, invstd (4*Cout)
   bool abn = false;              // algebraic BatchNorm backward (abn.hip): expanding 1x1 conv3 of a bottleneck, bf16 plans
+  size_t gram_off = 0;           // two-pass unit with Gram statistics: y^T y [128][Cin] + colsum(y) [Cin] of its input, forward -> backward
   bool fwd2p = false;            // ... and its raw output x never stored: two-pass forward (statistics, then conv + BatchNorm + residual + ReLU in the
                                  // epilogue), BatchNorm-backward x sums from the weight-gradient GEMM (blocks without a downsample branch)
   size_t abn_coef_off = 0;       // this unit's copy of cA | cB | cC (3*Cout floats) for the weight-gradient stream
@@ -241,8 +242,20 @@ int build_plan(Plan& p) {
         Unit& u = p.units[b.units.back()];
         if (!fwd2p_on || !u.abn || b.ds >= 0) continue;
         u.fwd2p = true;
-        const size_t sb = wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin);
+        size_t sb = wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin);
         if (sb > slab2) slab2 = sb;
+        // MMSKIN_FWDG (default 1): the first pass is not the convolution again but the Gram matrix of its INPUT (gram_stats, abn.hip);
+        // the backward pass reuses that matrix and runs g^T y alone
+        static const int fwdg_on = [] { const char* v = getenv("MMSKIN_FWDG"); return v ? atoi(v) : 1; }();
+        WgradRingPlan rg;
+        if (fwdg_on && wgrad_gram_plan((int)u.rows(), 0, u.s.Cin, rg, 2) && rg.gram_tiles == 1 &&
+            wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin, 1)) {
+          u.gram_off = carve(cur, ((size_t)128 + 1) * u.s.Cin * sizeof(float));
+          sb = wgrad_gram_slab_bytes((int)u.rows(), 0, u.s.Cin, 2);
+          if (sb > slab2) slab2 = sb;
+          sb = wgrad_gram_slab_bytes((int)u.rows(), u.s.Cout, u.s.Cin, 1);
+          if (sb > slab2) slab2 = sb;
+        }
       }
       if (slab2) {
         p.off_abn_sgx = carve(cur, 1024 * sizeof(float));
@@ -408,9 +421,21 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
       T* y = reinterpret_cast<T*>(ws + u.y_off);
       int nrows_u = 0;   // statistics row blocks this launch wrote (the launcher picks the tile height)
       const bool two_pass = training && u.fwd2p && i + 1 == nu && sizeof(T) == 2;
-      PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
-           launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, two_pass ? (T*)nullptr : x, training ? stat_sum : nullptr,
-                              training ? stat_sq : nullptr, st, nullptr, &nrows_u));
+      const bool gram_pass = two_pass && u.gram_off != 0;
+      if (gram_pass) {
+        if constexpr (sizeof(T) == 2) {
+          float* gm = reinterpret_cast<float*>(ws + u.gram_off);
+          float* gcs = gm + (size_t)128 * u.s.Cin;
+          PROF(K_BN_FWD, 0.0, (double)u.rows() * u.s.Cin * sizeof(T),
+               launch_wgrad_gram(u.s.N, u.s.OH(), u.s.OW(), u.s.Cin, u.s.Cout, nullptr, cur, reinterpret_cast<float*>(ws + p.off_abn_slab2), gm, gcs, st, 2));
+          if ((rc = gram_stats(gm, gcs, params + u.w_off, u.s.Cout, u.s.Cin, stat_sum, stat_sq, st))) return rc;
+          nrows_u = 1;
+        }
+      } else {
+        PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
+             launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, two_pass ? (T*)nullptr : x, training ? stat_sum : nullptr,
+                                training ? stat_sq : nullptr, st, nullptr, &nrows_u));
+      }
       if ((rc = bn_coeffs(u, nrows_u))) return rc;
       float* coef = reinterpret_cast<float*>(ws + u.coef_off);
       const int C = u.s.Cout;
@@ -420,7 +445,7 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
         // fp32 accumulator, not a bf16-rounded copy of it
         FwdFuse f2; f2.mul = coef; f2.bias = coef + C; f2.addend = in; f2.relu = true; f2.mask_out = ws + b.mask_off;
         // (class accounting: the recomputed MACs are overhead, not algorithmic work -- the layer's FLOPs were counted with the first pass)
-        PROF(K_CONV_FWD, 0.0, conv_bytes(u.s, sizeof(T), 0) + (double)u.rows() * C * sizeof(T), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f2));
+        PROF(K_CONV_FWD, gram_pass ? conv_flops(u.s) : 0.0, conv_bytes(u.s, sizeof(T), 0) + (double)u.rows() * C * sizeof(T), launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, y, nullptr, nullptr, st, &f2));
       } else if (i + 1 < nu) {
         PROF(K_BN_FWD, 0.0, 2.0 * u.rows() * C * sizeof(T), bn_apply<T>(x, nullptr, coef, coef + C, nullptr, nullptr, y, u.rows(), C, true, st));
       } else if (b.ds >= 0) {
@@ -608,7 +633,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
           float* S2 = reinterpret_cast<float*>(ws + p.off_abn_S2);
           p.prof.begin(K_WGRAD, st);
           rc = launch_wgrad_gram(ul.s.N, ul.s.OH(), ul.s.OW(), ul.s.Cin, ul.s.Cout, g, uin3, reinterpret_cast<float*>(ws + p.off_abn_slab2), S2,
-                                 reinterpret_cast<float*>(ws + p.off_abn_cs2), st);
+                                 reinterpret_cast<float*>(ws + p.off_abn_cs2), st, ul.gram_off ? 1 : 0);
           p.prof.end(st);
           if (p.prof.on) { p.prof.flops[K_WGRAD] += conv_flops(ul.s); p.prof.bytes[K_WGRAD] += conv_bytes(ul.s, sizeof(T)); }
           if (rc) return rc;
@@ -621,8 +646,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if constexpr (sizeof(T) == 2) {
           if ((rc = abn_prep(params + ul.w_off, cA, cA + ul.s.Cout, cA + 2 * ul.s.Cout, ul.s.Cout, ul.s.Cin, reinterpret_cast<bf16_t*>(ws + p.off_abn_wd),
                              reinterpret_cast<float*>(ws + p.off_abn_bias), reinterpret_cast<float*>(ws + ul.abn_coef_off), st))) return rc;
-          if (ul.fwd2p && (rc = abn_wgrad_finalize(reinterpret_cast<const float*>(ws + p.off_abn_S2), reinterpret_cast<const float*>(ws + p.off_abn_cs2), params + ul.w_off,
-                                                   reinterpret_cast<const float*>(ws + ul.abn_coef_off), ul.s.Cout, ul.s.Cin, grads + ul.w_off, st))) return rc;
+          const float* gkept = ul.gram_off ? reinterpret_cast<const float*>(ws + ul.gram_off) : nullptr;   // y^T y | colsum(y) from the forward pass
+          if (ul.fwd2p && (rc = abn_wgrad_finalize(reinterpret_cast<const float*>(ws + p.off_abn_S2),
+                                                   gkept ? gkept + (size_t)128 * ul.s.Cin : reinterpret_cast<const float*>(ws + p.off_abn_cs2), params + ul.w_off,
+                                                   reinterpret_cast<const float*>(ws + ul.abn_coef_off), ul.s.Cout, ul.s.Cin, grads + ul.w_off, st, gkept))) return rc;
         }
       }
       if (has_ds && !ds_branch) {

@@ -359,15 +359,15 @@ double mmskin_conv2d_dgrad_time(int N, int Cin, int H, int W, int Cout, int kh, 
 int64_t mmskin_abn_workspace_bytes(int N, int Cw, int C4, int H, int W) {
   const size_t M = (size_t)N * H * W;
   size_t b = 4096 + M * C4 * 2 + 2 * M * Cw * 2 + (size_t)Cw * (C4 + Cw) * 2 + 4 * (size_t)Cw + 12 * (size_t)C4;
-  b += wgrad_gram_slab_bytes((int)M, C4, Cw) + ((size_t)C4 + 256) * Cw * 4 + 16 * 256;
+  b += 2 * wgrad_gram_slab_bytes((int)M, C4, Cw) + wgrad_gram_slab_bytes((int)M, 0, Cw, 2) + ((size_t)C4 + 512) * Cw * 4 + 32 * 256;
   return (int64_t)b;
 }
-int mmskin_abn_backward(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
-                        int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+static int abn_backward_impl(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
+                             int C4, int H, int W, float* dy, float* dw, void* workspace, hipStream_t st, bool kept_gram) {
   Carver c(workspace);
   const size_t M = (size_t)N * H * W;
-  ARG_CHECK(wgrad_gram_slab_bytes((int)M, C4, Cw) > 0, "abn_backward: shape C4=%d Cw=%d unsupported", C4, Cw);
+  ARG_CHECK(wgrad_gram_slab_bytes((int)M, C4, Cw) > 0 && (!kept_gram || (wgrad_gram_slab_bytes((int)M, C4, Cw, 1) > 0 && wgrad_gram_slab_bytes((int)M, 0, Cw, 2) > 0)),
+            "abn_backward: shape C4=%d Cw=%d unsupported", C4, Cw);
   bf16_t* gh = c.take<bf16_t>(M * C4);
   bf16_t* yh = c.take<bf16_t>(M * Cw);
   bf16_t* dyh = c.take<bf16_t>(M * Cw);
@@ -376,7 +376,11 @@ int mmskin_abn_backward(const float* g, const float* y, const float* w, const fl
   float* coef = c.take<float>(3 * (size_t)C4);
   float* S = c.take<float>(((size_t)C4 + 256) * Cw);
   float* cs = c.take<float>(256);
-  float* slab = c.take<float>(wgrad_gram_slab_bytes((int)M, C4, Cw) / sizeof(float));
+  float* gram = c.take<float>((size_t)256 * Cw);
+  size_t sb = wgrad_gram_slab_bytes((int)M, C4, Cw);
+  if (wgrad_gram_slab_bytes((int)M, C4, Cw, 1) > sb) sb = wgrad_gram_slab_bytes((int)M, C4, Cw, 1);
+  if (wgrad_gram_slab_bytes((int)M, 0, Cw, 2) > sb) sb = wgrad_gram_slab_bytes((int)M, 0, Cw, 2);
+  float* slab = c.take<float>(sb / sizeof(float));
   int rc;
   if ((rc = nchw_to_nhwc<bf16_t>(g, N, C4, H, W, gh, st))) return rc;
   if ((rc = nchw_to_nhwc<bf16_t>(y, N, Cw, H, W, yh, st))) return rc;
@@ -386,8 +390,40 @@ int mmskin_abn_backward(const float* g, const float* y, const float* w, const fl
   f.in2 = yh; f.k2 = Cw; f.bias = bias;
   if ((rc = launch_conv_dgrad<bf16_t>(s, gh, wd, dyh, (const bf16_t*)nullptr, st, &f))) return rc;
   if ((rc = nhwc_to_nchw<bf16_t>(dyh, N, Cw, H, W, dy, st))) return rc;
+  if (kept_gram) {   // the two-pass forward's order: y^T y + colsum(y) first (forward), g^T y alone later
+    if ((rc = launch_wgrad_gram(N, H, W, Cw, C4, nullptr, yh, slab, gram, cs, st, 2))) return rc;
+    if ((rc = launch_wgrad_gram(N, H, W, Cw, C4, gh, yh, slab, S, nullptr, st, 1))) return rc;
+    return abn_wgrad_finalize(S, cs, w, coef, C4, Cw, dw, st, gram);
+  }
   if ((rc = launch_wgrad_gram(N, H, W, Cw, C4, gh, yh, slab, S, cs, st))) return rc;
   return abn_wgrad_finalize(S, cs, w, coef, C4, Cw, dw, st);
+}
+int mmskin_abn_backward(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N, int Cw,
+                        int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream) {
+  return abn_backward_impl(g, y, w, cA, cB, cC, N, Cw, C4, H, W, dy, dw, workspace, (hipStream_t)stream, false);
+}
+/* same result through the two-pass forward's kernels: Gram matrix + column sums of y in their own launch, g^T y alone */
+int mmskin_abn_backward_kept_gram(const float* g, const float* y, const float* w, const float* cA, const float* cB, const float* cC, int N,
+                                  int Cw, int C4, int H, int W, float* dy, float* dw, void* workspace, void* stream) {
+  return abn_backward_impl(g, y, w, cA, cB, cC, N, Cw, C4, H, W, dy, dw, workspace, (hipStream_t)stream, true);
+}
+/* Per-channel sum and sum of squares of x = conv1x1(y, w) (y [N,Cw,H,W], w [C4,Cw], bf16 operands) WITHOUT forming x: from the Gram
+ * matrix y^T y and the column sums of y (abn.hip gram_stats) -- the first pass of the two-pass BatchNorm forward.  Workspace as
+ * mmskin_abn_workspace_bytes. */
+int mmskin_conv1x1_gram_stats(const float* y, const float* w, int N, int Cw, int C4, int H, int W, float* stat_sum, float* stat_sq,
+                              void* workspace, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Carver c(workspace);
+  const size_t M = (size_t)N * H * W;
+  ARG_CHECK(wgrad_gram_slab_bytes((int)M, 0, Cw, 2) > 0, "conv1x1_gram_stats: Cw=%d unsupported", Cw);
+  bf16_t* yh = c.take<bf16_t>(M * Cw);
+  float* gram = c.take<float>((size_t)256 * Cw);
+  float* cs = c.take<float>(256);
+  float* slab = c.take<float>(wgrad_gram_slab_bytes((int)M, 0, Cw, 2) / sizeof(float));
+  int rc;
+  if ((rc = nchw_to_nhwc<bf16_t>(y, N, Cw, H, W, yh, st))) return rc;
+  if ((rc = launch_wgrad_gram(N, H, W, Cw, C4, nullptr, yh, slab, gram, cs, st, 2))) return rc;
+  return gram_stats(gram, cs, w, C4, Cw, stat_sum, stat_sq, st);
 }
 
 /* same for the weight-gradient kernel (+ its slab reduction) */

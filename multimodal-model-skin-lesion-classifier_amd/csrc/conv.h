@@ -108,10 +108,11 @@ int wgrad_ring_launch_count();
 // dY^T in plus in^T in and colsum(in) in one launch (1x1 / stride 1 layers whose Cout x Cin the ring kernel tiles): the slab rows are
 // [Cout main | gram tile rows]; returns the plan through r, reduces the slabs into s_out [Cout + gram rows][Cin] and the column sums
 // into colsum_out [Cin].  scratch: wgrad_gram_scratch_floats() floats behind the caller's slab.
-bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r);
-size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin);
+// mode 1: dY^T in only (no Gram rows, colsum_out untouched); mode 2: in^T in + colsum(in) only (g unused; s_out = [gram rows][Cin]).
+bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r, int mode = 0);
+size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin, int mode = 0);
 int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, const bf16_t* in, float* slab, float* s_out, float* colsum_out,
-                      hipStream_t st);
+                      hipStream_t st, int mode = 0);
 
 // Inference epilogue (eval-mode BatchNorm folded into the conv): out = [relu](acc + bias[c] + addend)
 struct FwdFuse {
@@ -209,5 +210,8 @@ int launch_wgrad3_ring(const ConvShape& s, const bf16_t* dout, const bf16_t* in,
 // algebraic BatchNorm backward of an expanding 1x1 convolution (abn.hip)
 int abn_prep(const float* W, const float* cA, const float* cB, const float* cC, int C4, int Cw, bf16_t* wd, float* bias, float* coef_copy,
              hipStream_t st);
-int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st);
+int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, const float* coef, int C4, int Cw, float* dW, hipStream_t st,
+                       const float* gram = nullptr);   // gram: y^T y kept from the forward pass (else the rows behind S's C4 main rows)
+// statistics (sum, sum of squares per output channel, one-row table) of x = y W^T from gram = y^T y [Cw][Cw] and colsum(y)
+int gram_stats(const float* gram, const float* colsum, const float* W, int C4, int Cw, float* stat_sum, float* stat_sq, hipStream_t st);
 int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStream_t st);

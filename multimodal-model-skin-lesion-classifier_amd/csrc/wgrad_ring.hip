@@ -324,11 +324,17 @@ bool wgrad_ring_tile(int M, int Cout, int Ktot, WgradRingPlan& r, bool simple) {
 }
 
 // ---- dY^T in, in^T in and colsum(in) in one launch (see conv.h)
-bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r) {
-  if (!wgrad_ring_tile(M, Cout, Cin, r, false)) return false;
+// mode 0: all three; mode 1: dY^T in only (the Gram matrix was kept by the forward pass); mode 2: in^T in and colsum(in) only (forward:
+// the statistics of an expanding 1x1 convolution's output follow from the Gram matrix of its input, abn.hip gram_stats)
+bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r, int mode) {
+  if (mode == 2) {
+    if (Cin % 64 || Cin > 256) return false;
+    r.wo = 2; r.wk = Cin % 128 == 0 ? 2 : 1;
+    Cout = 0;
+  } else if (!wgrad_ring_tile(M, Cout, Cin, r, mode == 1)) return false;
   const int BO = 64 * r.wo, G = 8 / (r.wo * r.wk), step = G * 32;
-  if (Cin % 8 || (uint64_t)M * Cout * 2 >= 0xE0000000ull) return false;
-  r.gram_tiles = ceil_div(Cin, BO);
+  if (Cin % 8 || (uint64_t)M * Cout * 2 >= 0xE0000000ull || (uint64_t)M * Cin * 2 >= 0xE0000000ull) return false;
+  r.gram_tiles = mode == 1 ? 0 : ceil_div(Cin, BO);
   const int tiles = (Cout / BO + r.gram_tiles) * (Cin / (64 * r.wk));
   static const int target = ring_env("MMSKIN_WGRAD_RING_BLOCKS", 256);
   int ns = target / tiles > 0 ? target / tiles : 1;
@@ -340,10 +346,10 @@ bool wgrad_gram_plan(int M, int Cout, int Cin, WgradRingPlan& r) {
   return true;
 }
 static size_t gram_colsum_floats(const WgradRingPlan& r) { return (size_t)r.nsplit * (8 / (r.wo * r.wk)) * r.gram_tiles * 64 * r.wo; }
-size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin) {
+size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin, int mode) {
   WgradRingPlan r;
-  if (!wgrad_gram_plan(M, Cout, Cin, r)) return 0;
-  const size_t rows = (size_t)Cout + (size_t)r.gram_tiles * 64 * r.wo;
+  if (!wgrad_gram_plan(M, Cout, Cin, r, mode)) return 0;
+  const size_t rows = (size_t)(mode == 2 ? 0 : Cout) + (size_t)r.gram_tiles * 64 * r.wo;
   return ((size_t)r.nsplit * rows * Cin + gram_colsum_floats(r)) * sizeof(float);
 }
 
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restri
     for (int j = 1; j < 16; ++j) { const float4 u = red[j][cx]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     s_out[i] = t;
   }
-  if (blockIdx.x == gridDim.x - 1) {   // column sums: Cin in {64, 128, 256} columns x (256 / Cin) row lanes over the np partial rows
+  if (blockIdx.x == gridDim.x - 1 && colsum_out) {   // column sums: Cin in {64, 128, 256} columns x (256 / Cin) row lanes over the np partial rows
     __syncthreads();
     float* redf = reinterpret_cast<float*>(red);
     const int col = threadIdx.x % Cin, ln = threadIdx.x / Cin, nl = 256 / Cin;
@@ -385,10 +391,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restri
 }
 
 int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, const bf16_t* in, float* slab, float* s_out, float* colsum_out,
-                      hipStream_t st) {
+                      hipStream_t st, int mode) {
   WgradRingPlan r;
   const int M = N * H * W;
-  ARG_CHECK(wgrad_gram_plan(M, Cout, Cin, r) && (Cin == 64 || Cin == 128 || Cin == 256), "wgrad_gram: shape Cout=%d Cin=%d not tiled by the ring kernel", Cout, Cin);
+  ARG_CHECK(wgrad_gram_plan(M, Cout, Cin, r, mode) && (Cin == 64 || Cin == 128 || Cin == 256), "wgrad_gram: shape Cout=%d Cin=%d not tiled by the ring kernel", Cout, Cin);
+  if (mode == 2) Cout = 0;
   WgradArgs a = {};
   a.dy = g; a.in = in; a.slab = slab;
   a.N = N; a.IH = H; a.IW = W; a.C = Cin; a.Cpitch = Cin; a.OH = H; a.OW = W;
@@ -401,7 +408,8 @@ int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, c
   const int total4 = (int)(rows * Cin / 4);
   const int G = 8 / (r.wo * r.wk);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ceil_div(total4, 16)), dim3(256), 0, st, reinterpret_cast<const float4*>(slab),
-                     reinterpret_cast<float4*>(s_out), r.nsplit, total4, a.colsum, colsum_out, r.nsplit * G, r.gram_tiles * 64 * r.wo, Cin);
+                     reinterpret_cast<float4*>(s_out), r.nsplit, total4, a.colsum, r.gram_tiles ? colsum_out : nullptr, r.nsplit * G,
+                     r.gram_tiles * 64 * r.wo, Cin);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -79,3 +79,68 @@ def test_algebraic_bn_backward_matches_fp64_reference(case):
     assert l2_emu < 1e-3, ("dy vs emulation", l2_emu)
     assert l2_ref < 6e-3 and e_dy < 5e-2, ("dy", l2_ref, e_dy)
     assert e_dw < 1e-3, ("dw", e_dw)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
+def test_kept_gram_order_of_the_two_pass_forward(case):
+    """The production order of the two-pass units: y^T y + colsum(y) by their own launch (forward), g^T y alone later (backward)
+    -- same dW as the one-launch form to fp32 summation order, same fp64 bound."""
+    N, Cw, C4, H, W = case
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(7 + sum(case))
+    y = torch.relu(torch.randn(N, Cw, H, W, generator=gen)).bfloat16().float()
+    g = (torch.randn(N, C4, H, W, generator=gen) * (torch.rand(N, C4, H, W, generator=gen) > 0.4)).bfloat16().float()
+    w = torch.randn(C4, Cw, generator=gen) / Cw ** 0.5
+    wb = w.bfloat16().double()
+    cA = (torch.rand(C4, generator=gen) + 0.5).double(); cB = (torch.randn(C4, generator=gen) * 0.05).double(); cC = (torch.randn(C4, generator=gen) * 0.02).double()
+    M = N * H * W
+    ym = y.double().permute(0, 2, 3, 1).reshape(M, Cw); gm = g.double().permute(0, 2, 3, 1).reshape(M, C4)
+    dw_ref = (cA * gm + cB * (ym @ wb.t()) + cC).t() @ ym
+    dev = [t.float().to(DEV) for t in (g, y, w, cA, cB, cC)]
+    wsp = ws(lib.mmskin_abn_workspace_bytes(N, Cw, C4, H, W))
+    out = []
+    for fn, launches in (("mmskin_abn_backward", 1), ("mmskin_abn_backward_kept_gram", 2)):
+        dy = torch.empty(N, Cw, H, W, device=DEV); dw = torch.empty(C4, Cw, device=DEV)
+        n0 = lib.mmskin_wgrad_ring_launches()
+        call(fn, *[ptr(t) for t in dev], N, Cw, C4, H, W, ptr(dy), ptr(dw), ptr(wsp), stream())
+        torch.cuda.synchronize()
+        assert lib.mmskin_wgrad_ring_launches() == n0 + launches
+        out.append((dy.cpu(), dw.cpu()))
+    assert torch.equal(out[0][0], out[1][0])                       # dy does not involve the Gram matrix
+    e = rel_err(out[1][1], dw_ref)
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(dict(test="abn_backward_kept_gram", case=list(case), dw_max_err_over_rms=e,
+                                dw_vs_one_launch=rel_err(out[1][1], out[0][1].double()))) + "\n")
+    assert e < 1e-3, e
+
+
+@pytest.mark.parametrize("case", CASES + [(256, 64, 256, 56, 56)], ids=[f"c{i}" for i in range(len(CASES) + 1)])
+def test_conv1x1_statistics_from_the_gram_matrix(case):
+    """sum x and sum x^2 per channel of x = conv1x1(y, w) from y^T y and colsum(y) (first pass of the two-pass BatchNorm forward) against
+    the fp64 sums of the fp64 product: relative error of the mean and of the variance <= 2e-5 (fp32 Gram entries, double contraction).
+    The last case is layer1's production shape (802 816 rows)."""
+    N, Cw, C4, H, W = case
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(11 + sum(case))
+    y = (torch.relu(torch.randn(N, Cw, H, W, generator=gen) + 0.3)).bfloat16().float()
+    w = torch.randn(C4, Cw, generator=gen) / Cw ** 0.5
+    wb = w.bfloat16().double()
+    M = N * H * W
+    ym = y.permute(0, 2, 3, 1).reshape(M, Cw)
+    s_ref = torch.zeros(C4, dtype=torch.float64); q_ref = torch.zeros(C4, dtype=torch.float64)
+    for i in range(0, M, 65536):
+        x = ym[i:i + 65536].double() @ wb.t()
+        s_ref += x.sum(0); q_ref += (x * x).sum(0)
+    ssum = torch.empty(C4, device=DEV); ssq = torch.empty(C4, device=DEV)
+    wsp = ws(lib.mmskin_abn_workspace_bytes(N, Cw, C4, H, W))
+    yd, wd = y.to(DEV), w.to(DEV)
+    call("mmskin_conv1x1_gram_stats", ptr(yd), ptr(wd), N, Cw, C4, H, W, ptr(ssum), ptr(ssq), ptr(wsp), stream())
+    torch.cuda.synchronize()
+    mean_ref, var_ref = s_ref / M, q_ref / M - (s_ref / M) ** 2
+    mean = ssum.double().cpu() / M
+    var = ssq.double().cpu() / M - mean ** 2
+    e_mean = float(((mean - mean_ref).abs() / var_ref.sqrt()).max())
+    e_var = float(((var - var_ref).abs() / var_ref).max())
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(dict(test="conv1x1_gram_stats", case=list(case), mean_err_over_std=e_mean, var_rel_err=e_var)) + "\n")
+    assert e_mean < 2e-5 and e_var < 2e-5, (e_mean, e_var)

@@ -23,7 +23,9 @@ def _chk(a, b, tol=1e-4):
     assert (a - b).abs().max().item() <= tol * max(1.0, b.abs().max().item()), (a - b).abs().max().item()
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 96), (3, 7, 9, 192), (1, 56, 56, 96), (5, 3, 4, 384), (2, 1, 1, 768), (2, 28, 28, 100)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 14, 14, 96), (3, 7, 9, 192), (1, 56, 56, 96), (5, 3, 4, 384), (2, 1, 1, 768), (2, 28, 28, 100),
+                                     # EfficientNet-B0 / B7 expanded widths of the stride-1 3x3 depthwise layers (C/4 = 36, 60, 336, 960, 16): ADVICE r03
+                                     (2, 9, 11, 144), (1, 12, 12, 240), (1, 7, 7, 1344), (1, 5, 6, 3840), (2, 10, 10, 64)])
 def test_dwconv3_forward_backward(N, H, W, C):
     g = torch.Generator().manual_seed(N * 1000 + H + C)
     x = torch.randn(N, H, W, C, generator=g)
