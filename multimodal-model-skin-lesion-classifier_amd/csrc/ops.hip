@@ -435,14 +435,17 @@ int bn_bwd_reduce(const T* dy, const T* x, const T* ymask, const float* scale, c
   return MMSKIN_OK;
 }
 
-template <typename IN, int RL = 4>
-__global__ __launch_bounds__(64 * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
+// CB columns x RL row lanes per block.  CB = 16 (256 threads, 4 KB of LDS) is the backward pass's form: a block that small fits on a CU
+// beside a weight-gradient ring workgroup of the other stream (208 VGPRs x 8 waves, 121 - 132 KB of LDS), where the 1024-thread form
+// waited for a ring workgroup to retire -- i.e. for the whole weight-gradient launch (profiles/r04_experiments.txt (9)).
+template <typename IN, int RL = 4, int CB = 64>
+__global__ __launch_bounds__(CB * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                        float* cA, float* cB, float* cC, int n_grad, int acc_bc, const float* __restrict__ s2_override = nullptr) {
-  __shared__ double red[2][RL][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ double red[2][RL][CB];
+  const int cx = threadIdx.x % CB, ry = threadIdx.x / CB;
+  const int c = blockIdx.x * CB + cx;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int r = ry;
@@ -487,8 +490,13 @@ int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const 
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<double>, dim3(ceil_div(C, 64)), dim3(256), 0, st, scratch, G, C, count,
                        gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
   } else if (nrows > 64) {
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nrows, C, count,
-                       gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
+    static const int small_blocks = [] { const char* e = getenv("MMSKIN_BNB_SMALL_BLOCKS"); return e ? atoi(e) : 1; }();
+    if (small_blocks)
+      hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16, 16>), dim3(ceil_div(C, 16)), dim3(256), 0, st, partial, nrows, C, count,
+                         gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
+    else
+      hipLaunchKernelGGL((bn_bwd_finalize_kernel<float, 16>), dim3(ceil_div(C, 64)), dim3(1024), 0, st, partial, nrows, C, count,
+                         gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
   } else {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<float>, dim3(ceil_div(C, 64)), dim3(256), 0, st, partial, nrows, C, count,
                        gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);

@@ -353,17 +353,47 @@ size_t wgrad_gram_slab_bytes(int M, int Cout, int Cin, int mode) {
   return ((size_t)r.nsplit * rows * Cin + gram_colsum_floats(r)) * sizeof(float);
 }
 
-// sum the split slabs [nsplit][rows][Cin] -> s_out [rows][Cin] and the colsum partials [np][wpad] -> colsum_out [Cin].
-// The output is small (8 - 24 K float4) and the slab count large: 16 float4 columns x 16 slab lanes per block, the lanes meet in LDS
-// (one thread per column walking every slab ran 32 blocks for 95 us).  Deterministic (fixed order).
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restrict__ slab, float4* __restrict__ s_out, int nsplit, int total4,
+// sum the split slabs [nsplit][rows][Cin] -> s_out [rows][Cin] (blocks < nmain) and the colsum partials [np][wpad] -> colsum_out [Cin]
+// (the blocks behind them, 16 columns each).  The output is small (8 - 24 K float4) and the slab count large: 16 columns x 16 slab / row
+// lanes per block with two / four independent loads in flight, the lanes meet in LDS (one thread per column walking every slab ran 32
+// blocks for 95 us; the column sums as the tail of ONE block, 1024 partial rows over four lanes, 39 us).  Deterministic (fixed order).
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restrict__ slab, float4* __restrict__ s_out, int nsplit, int total4, int nmain,
                                                           const float* __restrict__ cpart, float* __restrict__ colsum_out, int np, int wpad, int Cin) {
   __shared__ float4 red[16][16];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  if ((int)blockIdx.x >= nmain) {   // column sums
+    float* redf = reinterpret_cast<float*>(red);
+    const int col = ((int)blockIdx.x - nmain) * 16 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (col < Cin) {
+      int k = ry;
+      for (; k + 48 < np; k += 64) {
+        s0 += cpart[(size_t)k * wpad + col]; s1 += cpart[(size_t)(k + 16) * wpad + col];
+        s2 += cpart[(size_t)(k + 32) * wpad + col]; s3 += cpart[(size_t)(k + 48) * wpad + col];
+      }
+      for (; k < np; k += 16) s0 += cpart[(size_t)k * wpad + col];
+    }
+    redf[ry * 16 + cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ry == 0 && col < Cin) {
+      float t = redf[cx];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) t += redf[j * 16 + cx];
+      colsum_out[col] = t;
+    }
+    return;
+  }
   const int i = blockIdx.x * 16 + cx;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < total4)
-    for (int k = ry; k < nsplit; k += 16) { const float4 u = slab[(size_t)k * total4 + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (i < total4) {
+    int k = ry;
+    for (; k + 16 < nsplit; k += 32) {
+      const float4 u = slab[(size_t)k * total4 + i], v = slab[(size_t)(k + 16) * total4 + i];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (k < nsplit) { const float4 u = slab[(size_t)k * total4 + i]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
   red[ry][cx] = a;
   __syncthreads();
   if (ry == 0 && i < total4) {
@@ -371,22 +401,6 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float4* __restri
 #pragma unroll
     for (int j = 1; j < 16; ++j) { const float4 u = red[j][cx]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
     s_out[i] = t;
-  }
-  if (blockIdx.x == gridDim.x - 1 && colsum_out) {   // column sums: Cin in {64, 128, 256} columns x (256 / Cin) row lanes over the np partial rows
-    __syncthreads();
-    float* redf = reinterpret_cast<float*>(red);
-    const int col = threadIdx.x % Cin, ln = threadIdx.x / Cin, nl = 256 / Cin;
-    float s0 = 0.f, s1 = 0.f;
-    int k = ln;
-    for (; k + nl < np; k += 2 * nl) { s0 += cpart[(size_t)k * wpad + col]; s1 += cpart[(size_t)(k + nl) * wpad + col]; }
-    if (k < np) s0 += cpart[(size_t)k * wpad + col];
-    redf[threadIdx.x] = s0 + s1;
-    __syncthreads();
-    if (ln == 0) {
-      float s = redf[col];
-      for (int j = 1; j < nl; ++j) s += redf[j * Cin + col];
-      colsum_out[col] = s;
-    }
   }
 }
 
@@ -407,9 +421,9 @@ int launch_wgrad_gram(int N, int H, int W, int Cin, int Cout, const bf16_t* g, c
   if (rc) return rc;
   const int total4 = (int)(rows * Cin / 4);
   const int G = 8 / (r.wo * r.wk);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ceil_div(total4, 16)), dim3(256), 0, st, reinterpret_cast<const float4*>(slab),
-                     reinterpret_cast<float4*>(s_out), r.nsplit, total4, a.colsum, r.gram_tiles ? colsum_out : nullptr, r.nsplit * G,
-                     r.gram_tiles * 64 * r.wo, Cin);
+  const int nmain = ceil_div(total4, 16), ncs = (r.gram_tiles && colsum_out) ? ceil_div(Cin, 16) : 0;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(nmain + ncs), dim3(256), 0, st, reinterpret_cast<const float4*>(slab),
+                     reinterpret_cast<float4*>(s_out), r.nsplit, total4, nmain, a.colsum, colsum_out, r.nsplit * G, r.gram_tiles * 64 * r.wo, Cin);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }
