@@ -43,13 +43,15 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, float* __res
 // ------------------------------------------------------------------ generic strided f32 GEMM
 // C[m][n] = sum_k A(m,k) * B(n,k) (+ bias[n]) ; A(m,k) = a[m*sam + k*sak] ; B(n,k) = b[n*sbn + k*sbk]
 // The head's GEMMs have M = batch (256) and N, K <= 2048: tiny for a 256-CU chip, so the kernel is built
-// for latency, not throughput: 32x32 output tiles (many workgroups), K-steps of 32 with the next step's
-// operands prefetched into registers while the current one is multiplied on the exact-f32 MFMA
+// for latency, not throughput: 32x32 output tiles (many workgroups), K-steps of 128 (16 + 16 independent loads per thread in flight;
+// with K-steps of 32 a K = 512 GEMM was 16 dependent load -> barrier -> multiply rounds, 12 - 16 us for 0.13 GFLOP) with the next
+// step's operands prefetched into registers while the current one is multiplied on the exact-f32 MFMA
 // (v_mfma_f32_16x16x4_f32, one 16x16 fragment per wave).
-#define LG_BK 32
+#define LG_BK 128
 #define LG_T 32
-#define LG_PK 36   // pitch of a [row][k] tile (k-contiguous source)
+#define LG_PK 130  // pitch of a [row][k] tile (k-contiguous source): 2 row + g distinct over a half wave's 16 rows x 2 k
 #define LG_PM 48   // pitch of a [k][row] tile (row-contiguous source)
+#define LG_EPT (LG_T * LG_BK / 256)   // elements per thread and operand
 template <bool KC> __device__ __forceinline__ int lg_idx(int row, int k) { return KC ? row * LG_PK + k : k * LG_PM + row; }
 
 template <bool A_KC, bool B_KC>
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        int N, int K, int64_t sam, int64_t sak, int64_t sbn,
                                                        int64_t sbk, int64_t ldc, int relu, int kchunk, int64_t sab,
                                                        int64_t sbb, int64_t scb) {
-  __shared__ float As[LG_BK * LG_PM];
-  __shared__ float Bs[LG_BK * LG_PM];
+  __shared__ float As[LG_BK * LG_PM > LG_T * LG_PK ? LG_BK * LG_PM : LG_T * LG_PK];
+  __shared__ float Bs[LG_BK * LG_PM > LG_T * LG_PK ? LG_BK * LG_PM : LG_T * LG_PK];
   if (kchunk < 0) {   // batched: blockIdx.z = batch index (no split-K)
     a += (int64_t)blockIdx.z * sab; b += (int64_t)blockIdx.z * sbb; c += (int64_t)blockIdx.z * scb;
   }
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int m0 = blockIdx.y * LG_T, n0 = blockIdx.x * LG_T;
   const int wm = wid >> 1, wn = wid & 1;
   f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float ra[4], rb[4];
-  // element e = tid + 256*i of a 32x32 tile: k-contiguous sources walk k fastest, else rows fastest
-  auto coords = [&](bool kc, int e, int& row, int& kk) { if (kc) { row = e >> 5; kk = e & 31; } else { row = e & 31; kk = e >> 5; } };
+  float ra[LG_EPT], rb[LG_EPT];
+  // element e = tid + 256*i of a 32 x LG_BK tile: k-contiguous sources walk k fastest, else rows fastest
+  auto coords = [&](bool kc, int e, int& row, int& kk) { if (kc) { row = e / LG_BK; kk = e % LG_BK; } else { row = e % LG_T; kk = e / LG_T; } };
 #define LG_FETCH(k0)                                                                                    \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                       \
+  _Pragma("unroll") for (int i = 0; i < LG_EPT; ++i) {                                                  \
     int row, kk;                                                                                        \
     coords(A_KC, tid + 256 * i, row, kk);                                                               \
     ra[i] = (m0 + row < M && (k0) + kk < K) ? a[(int64_t)(m0 + row) * sam + (int64_t)((k0) + kk) * sak] : 0.f; \
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   LG_FETCH(0)
   for (int k0 = 0; k0 < K; k0 += LG_BK) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < LG_EPT; ++i) {
       int row, kk;
       coords(A_KC, tid + 256 * i, row, kk);
       As[lg_idx<A_KC>(row, kk)] = ra[i];
