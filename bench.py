@@ -328,7 +328,11 @@ def main():
     meta = {k: v.to(device) for k, v in meta.items()} if isinstance(meta, dict) else meta.to(device)
     label = torch.randint(0, 6, (B,), generator=g).to(device)
     crit = nn.CrossEntropyLoss(weight=torch.tensor([0.6, 1.7, 0.9, 1.2, 0.4, 2.1], device=device))
-    opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)   # train_pad_20.py:54
+    # train_pad_20.py:54.  mmskin.optim.Adam = torch.optim.Adam with one launch for the backbone's flat parameter arena (the head's
+    # parameters take torch's fused step); MMSKIN_TORCH_ADAM=1: torch's optimizer for everything (A/B)
+    from mmskin.optim import Adam as ArenaAdam
+    adam_cls = torch.optim.Adam if os.environ.get("MMSKIN_TORCH_ADAM", "0") == "1" else ArenaAdam
+    opt = adam_cls(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)
 
     def infer_step():
         with torch.no_grad():

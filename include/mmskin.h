@@ -214,6 +214,11 @@ int mmskin_gated_mix_backward(const float* dout, const float* z, const float* a,
 int mmskin_metablock_gate_forward(const float* V, const float* t1, const float* t2, float* out, int64_t n, void* stream);
 int mmskin_metablock_gate_backward(const float* dout, const float* V, const float* t1, const float* t2, float* dV,
                                    float* dt1, float* dt2, int64_t n, void* stream);
+/* One Adam step (torch.optim.Adam: g += weight_decay p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps)) over one flat fp32 range of n elements: parameters, gradient,
+ * both moments; step counts from 1; 16-byte aligned pointers.  The optimizer step of train_pad_20.py:54,113 for a parameter arena. */
+int mmskin_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int64_t step, void* stream);
 /* inverted dropout with a counter-based generator; mask[n] bytes (1 keep / 0 drop) */
 int mmskin_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t n, float p, uint64_t seed,
                            uint64_t offset, void* stream);

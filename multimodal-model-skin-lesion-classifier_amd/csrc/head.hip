@@ -1791,6 +1791,43 @@ int mmskin_attn_dropout_forward(const float* x, float* y, uint8_t* mask, int64_t
   ARG_CHECK(L > 0 && n % L == 0, "attn_dropout_forward: n=%lld is not rows x L=%d", (long long)n, L);
   EW_LAUNCH(attn_dropout_fwd_kernel, n, x, y, mask, n, L, p, seed, offset);
 }
+// ---- Adam (torch.optim.Adam semantics: L2 weight decay added to the gradient, bias-corrected moments) over ONE flat fp32 range:
+// the optimizer step of the reference's training loop (train_pad_20.py:54,113) as a single pass over the backbone's parameter arena
+// instead of torch's multi-tensor launches (6 x 49 us for ResNet-50).  16-byte accesses; n % 4 handled by a scalar tail.
+__global__ __launch_bounds__(256) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        int64_t n, float step_size, float b1c, float b2, float b2c, float eps, float wd, float inv_bc2_sqrt) {   // b1c = 1 - beta1, b2c = 1 - beta2 (formed in double on the host, like torch's scalars)
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  auto upd = [&](float& pv, float gv, float& mv, float& vv) {
+    gv += wd * pv;
+    mv += b1c * (gv - mv);
+    vv = b2 * vv + b2c * gv * gv;
+    pv -= step_size * mv / (sqrtf(vv) * inv_bc2_sqrt + eps);
+  };
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
+  }
+}
+int mmskin_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int64_t step, void* stream) {
+  ARG_CHECK(step >= 1 && n >= 0 && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: step=%lld / 16-byte alignment", (long long)step);
+  if (n == 0) return MMSKIN_OK;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), p, g, m, v, n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(1.0 / sqrt(bc2)));
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
 int mmskin_dropout_backward(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
   EW_LAUNCH(dropout_bwd_kernel, n, dy, mask, dx, n, p);
 }

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "mmskin_wgrad3_ring_launches": (_i64, []),
     "mmskin_abn_workspace_bytes": (_i64, [_i] * 5),
     "mmskin_abn_backward": (_i, [_P] * 6 + [_i] * 5 + [_P, _P, _P, _P]),
+    "mmskin_adam_step": (_i, [_P] * 4 + [_i64] + [ctypes.c_double] * 5 + [_i64, _P]),
     "mmskin_abn_backward_kept_gram": (_i, [_P] * 6 + [_i] * 5 + [_P, _P, _P, _P]),
     "mmskin_conv1x1_gram_stats": (_i, [_P, _P] + [_i] * 5 + [_P, _P, _P, _P]),
     "mmskin_batchnorm_workspace_bytes": (_i64, [_i] * 4),
