@@ -118,6 +118,7 @@ int mmskin_conv2d_dgrad_fused(const float* dy, const float* w, const float* xc, 
                               int pad, void* workspace, void* stream);
 /* launches of the layer-1 all-taps 3x3 kernel (csrc/conv3x3_c64.hip) since load */
 int64_t mmskin_conv3x3_c64_launches(void);
+int64_t mmskin_stem7x7_launches(void);   /* ... of the direct 7x7 stem convolution (stem7x7.hip) */
 /* timing helper for kernel tuning: average microseconds of the forward conv kernel over `iters` launches
  * on NHWC buffers carved from `workspace` (>= conv2d_workspace_bytes; contents irrelevant) */
 double mmskin_conv2d_time(int N, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dtype,

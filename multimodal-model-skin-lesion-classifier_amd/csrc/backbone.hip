@@ -380,10 +380,11 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
   if (norm6) PROF(K_STEM_MISC, 0.0, 0.0, stem_pack_u8<T>((const uint8_t*)image, p.N, p.H, p.W, p.Hp, p.Wp, norm6, img4, st));
   else PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>((const float*)image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + u0.x_off);
+  int stem_rows = 0;
   PROF(K_CONV_FWD, conv_flops(u0.s), conv_bytes(u0.s, sizeof(T)),
        launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + u0.wf_off, x0,
-                               training ? stat_sum : nullptr, training ? stat_sq : nullptr, st));
-  if ((rc = bn_coeffs(u0, stem_conv_stat_rows(p.N, p.OH0, p.OW0)))) return rc;
+                               training ? stat_sum : nullptr, training ? stat_sq : nullptr, st, &stem_rows));
+  if ((rc = bn_coeffs(u0, stem_rows))) return rc;
   float* c0 = reinterpret_cast<float*>(ws + u0.coef_off);
   T* pool = reinterpret_cast<T*>(ws + p.off_pool);
   PROF(K_STEM_MISC, 0.0, 0.0, stem_bn_relu_pool<T>(x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, pool, ws + p.off_idx, st));

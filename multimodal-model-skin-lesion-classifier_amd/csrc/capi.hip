@@ -187,8 +187,9 @@ int stem_fwd_core(StemWs<T>& s, const float* x, const float* w, const float* gam
   int rc;
   if ((rc = stem_pack<T>(x, N, H, W, g.Hp, g.Wp, s.img4, st))) return rc;
   if ((rc = stage_one<T>(w, 64, 3, 49, true, s.wv, (T*)nullptr, s.table, st))) return rc;
-  if ((rc = launch_stem_conv_fwd<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.img4, s.wv, s.x0, s.ssum, s.ssq, st))) return rc;
-  if ((rc = bn_finalize(s.ssum, s.ssq, stem_conv_stat_rows(N, g.OH, g.OW), 64, (double)N * g.OH * g.OW, gamma, beta, eps,
+  int stem_rows = 0;
+  if ((rc = launch_stem_conv_fwd<T>(N, g.OH, g.OW, g.Hp, g.Wp, s.img4, s.wv, s.x0, s.ssum, s.ssq, st, &stem_rows))) return rc;
+  if ((rc = bn_finalize(s.ssum, s.ssq, stem_rows, 64, (double)N * g.OH * g.OW, gamma, beta, eps,
                         0.1f, nullptr, nullptr, s.coef, s.coef + 64, s.coef + 128, s.coef + 192, s.red, st))) return rc;
   return stem_bn_relu_pool<T>(s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.pool, s.idx, st);
 }

@@ -169,8 +169,13 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
 // NHWC4 image produced by stem_pack (see stem.hip).  out = [N][OH][OW][64].
 template <typename T>
 int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, const T* wv, T* out,
-                         float* stat_sum, float* stat_sq, hipStream_t st);
-int stem_conv_stat_rows(int N, int OH, int OW);
+                         float* stat_sum, float* stat_sq, hipStream_t st, int* stat_rows_out = nullptr);
+int stem_conv_stat_rows(int N, int OH, int OW);   // upper bound of the statistics rows a launch writes (allocation); the launch reports its own count
+// direct 7x7 / stride 2 convolution from an LDS-resident input window (stem7x7.hip; bf16, 112-wide output rows): launch_stem_conv_fwd routes to it
+bool stem7x7_takes(int OH, int OW, int Hp, int Wp);
+int stem7x7_stat_rows(int N, int OH);
+int launch_stem7x7_fwd(int N, int OH, int OW, int Hp, int Wp, const bf16_t* img4, const bf16_t* wv, bf16_t* out, float* stat_sum, float* stat_sq,
+                       hipStream_t st);
 
 // VGG's first conv (3x3 s1 p1, Cin=3) as a virtual conv over the zero-bordered NHWC8 image of pack_nhwc8: one tap
 // per kernel row, each reading 32 contiguous elements (4 pixels x 8 ch; 3 x 3 of them carry weights), plus one

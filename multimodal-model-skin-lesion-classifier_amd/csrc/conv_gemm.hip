@@ -1085,7 +1085,14 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
 
 template <typename T>
 int launch_stem_conv_fwd(int N, int OH, int OW, int Hp, int Wp, const T* img4, const T* wv, T* out,
-                         float* stat_sum, float* stat_sq, hipStream_t st) {
+                         float* stat_sum, float* stat_sq, hipStream_t st, int* stat_rows_out) {
+  if constexpr (sizeof(T) == 2) {
+    if (stem7x7_takes(OH, OW, Hp, Wp)) {   // direct convolution from an LDS-resident window (stem7x7.hip)
+      if (stat_rows_out) *stat_rows_out = stem7x7_stat_rows(N, OH);
+      return launch_stem7x7_fwd(N, OH, OW, Hp, Wp, img4, wv, out, stat_sum, stat_sq, st);
+    }
+  }
+  if (stat_rows_out) *stat_rows_out = stem_conv_stat_rows(N, OH, OW);
   // virtual conv: macro pixel = 2 real pixels x 4 channels = 8 elements; one tap per kernel row r,
   // each reading 32 contiguous elements (8 real pixels x 4 ch) starting at macro pixel wo.
   ConvGemmArgs a = {};
@@ -1130,6 +1137,6 @@ int launch_vgg_first_conv_fwd(int N, int H, int W, int Hp, int Wp, const T* img8
   template int launch_vgg_first_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, const FwdFuse*, hipStream_t, int, float*, float*); \
   template int launch_conv_fwd<T>(const ConvShape&, const T*, const T*, T*, float*, float*, hipStream_t, const FwdFuse*, int*); \
   template int launch_conv_dgrad<T>(const ConvShape&, const T*, const T*, T*, const T*, hipStream_t, DgradFuse*);      \
-  template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t);
+  template int launch_stem_conv_fwd<T>(int, int, int, int, int, const T*, const T*, T*, float*, float*, hipStream_t, int*);
 INST(float)
 INST(bf16_t)

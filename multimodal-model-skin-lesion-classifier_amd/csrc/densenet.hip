@@ -285,12 +285,13 @@ int dense_forward(DensePlan& p, const void* image, const float* norm6, const flo
   else PROF(K_STEM_MISC, 0.0, 0.0, stem_pack<T>((const float*)image, p.N, p.H, p.W, p.Hp, p.Wp, img4, st));
   T* x0 = reinterpret_cast<T*>(ws + p.x0_off);
   ConvShape s0 = {p.N, p.H, p.W, 3, 64, 7, 7, 2, 3};
+  int stem_rows = 0;
   PROF(K_CONV_FWD, conv_flops(s0), conv_bytes(s0, sizeof(T)),
        launch_stem_conv_fwd<T>(p.N, p.OH0, p.OW0, p.Hp, p.Wp, img4, wf + p.wf0, x0, training ? stat_sum : nullptr,
-                               training ? stat_sq : nullptr, st));
+                               training ? stat_sq : nullptr, st, &stem_rows));
   float* c0 = reinterpret_cast<float*>(ws + p.coef0_off);
   if (training) {
-    PROF(K_BN_FWD, 0.0, 0.0, bn_finalize(stat_sum, stat_sq, stem_conv_stat_rows(p.N, p.OH0, p.OW0), 64, (double)p.N * p.OH0 * p.OW0,
+    PROF(K_BN_FWD, 0.0, 0.0, bn_finalize(stat_sum, stat_sq, stem_rows, 64, (double)p.N * p.OH0 * p.OW0,
                      params + p.n0.g_off, params + p.n0.b_off, eps, mom, buffers + p.n0.rm_off, buffers + p.n0.rv_off,
                      c0, c0 + 64, c0 + 128, c0 + 192, red, st));
   } else {

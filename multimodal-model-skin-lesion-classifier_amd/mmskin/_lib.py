@@ -61,6 +61,7 @@ _SIGNATURES = {
     "mmskin_conv_pipe_launches": (_i64, []),
     "mmskin_wgrad_ring_launches": (_i64, []),
     "mmskin_conv3x3_c64_launches": (_i64, []),
+    "mmskin_stem7x7_launches": (_i64, []),
     "mmskin_conv2d_dgrad_fused_rows": (_i, [_i] * 9),
     "mmskin_conv2d_dgrad_fused": (_i, [_P] * 8 + [_i] * 9 + [_P, _P]),
     "mmskin_wgrad3_ring_launches": (_i64, []),
