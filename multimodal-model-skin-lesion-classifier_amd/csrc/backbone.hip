@@ -695,6 +695,8 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
         if ((rc = bn_backward_fused(up, dY, partial, f.rows_written, dX))) return rc;
       } else {
         const T* addend = dz_final;
+        bool ds_addend_compact = false;
+        static const bool ds_compact = [] { const char* v = getenv("MMSKIN_DS_COMPACT"); return !v || atoi(v) != 0; }();
         if (has_ds) {
           Unit& d = p.units[b.ds];
           if ((rc = g_acquire(gin, ds_branch ? p.side.s2 : nullptr))) return rc;
@@ -708,11 +710,21 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
             DgradFuse fd;
             fd.in2 = in; fd.k2 = d.s.Cin; fd.bias = reinterpret_cast<const float*>(ws + p.off_abn_bias2);
             PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, g, reinterpret_cast<const T*>(ws + p.off_abn_wd2), gin, (const T*)nullptr, st, &fd));
+          } else if (ds_compact && bi > 0 && d.s.kh == 1 && d.s.stride == 2 && d.s.pad == 0 && u.s.kh == 1 && u.s.stride == 1) {
+            // Stride-2 1x1 downsample: its data gradient lives on the even pixels only.  It is computed as the dense GEMM over the pixels the
+            // convolution read (a 1x1 / stride 1 launch on the OH x OW grid) into a COMPACT buffer, and conv1's dgrad adds it at the even
+            // pixels in its epilogue: the zero fill of the other three quarters (154 + 77 + 38 MB written, then read back as the addend)
+            // and its launches are gone.
+            if ((rc = wgrad_async(d, 2, in))) return rc;
+            ConvShape dc = d.s;
+            dc.H = d.s.OH(); dc.W = d.s.OW(); dc.stride = 1;
+            PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(dc, dXd, wd + d.wd_off, S[3], (const T*)nullptr, st));
+            ds_addend_compact = true;
           } else {
             if ((rc = wgrad_async(d, 2, in))) return rc;
             PROF(K_CONV_DGRAD, conv_flops(d.s), conv_bytes(d.s, sizeof(T)), launch_conv_dgrad<T>(d.s, dXd, wd + d.wd_off, gin, (const T*)nullptr, st));
           }
-          addend = gin;   // main-branch dgrad accumulates on top, in place
+          addend = ds_addend_compact ? S[3] : gin;   // main-branch dgrad accumulates on top (in place unless the branch's gradient is compact)
         }
         if ((rc = g_acquire(gin))) return rc;
         DgradFuse f;
@@ -722,6 +734,7 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
           Unit& pu = p.units[pb.units.back()];
           f.mask_bits = ws + pb.mask_off; f.x = pu.fwd2p ? nullptr : ws + pu.x_off; f.partial = partial;   // two-pass unit: no raw output to take sums against
           if (pb.ds >= 0) { f.x2 = ws + p.units[pb.ds].x_off; f.partial_b = partial_b; }
+          f.addend_s2 = ds_addend_compact;
           fp = &f;
         }
         PROF(K_CONV_DGRAD, conv_flops(u.s), conv_bytes(u.s, sizeof(T), 1 + (fp ? (f.x2 ? 3 : 2) : 0)), launch_conv_dgrad<T>(u.s, dX, wd + u.wd_off, gin, addend, st, fp));

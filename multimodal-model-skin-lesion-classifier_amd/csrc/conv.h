@@ -66,6 +66,8 @@ struct ConvGemmArgs {
   // 128-row kernels only.
   const void* in2;
   int K1, pitch2_shift;
+  int addend_sub;          // 2: addend is the stride-2 SAMPLED tensor [N][ceil(OHf/2)][ceil(OWf/2)][Cout] (a stride-2 1x1 convolution's data gradient,
+                           // kept compact): only even (y, x) output pixels have an addend row.  1x1 / stride 1 launches only.
   const float* ep_mul;     // light-epilogue launches: per-output-channel multiplier applied to the accumulator BEFORE bias / addend (train-mode BatchNorm scale)
   uint8_t* ep_mask_out;    // light-epilogue launches: also write the ReLU mask of the stored tile, one byte per 16-byte chunk, bit e = (stored value e > 0)
                            // (the forward's second pass of a two-pass conv + BatchNorm + residual + ReLU, backbone.hip)
@@ -155,6 +157,7 @@ struct DgradFuse {
   const void* in2 = nullptr;
   int k2 = 0;
   const float* bias = nullptr;  // [Cin] fp32, added before the mask
+  bool addend_s2 = false;       // the addend is compact: [N][ceil(H/2)][ceil(W/2)][Cin], added at the even pixels (see ConvGemmArgs::addend_sub)
 };
 int conv_dgrad_partial_rows(const ConvShape& s);
 

@@ -519,6 +519,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
     const int img = mm / ab, rem = mm - img * ab;
     const int a = rem / b_dim, b = rem - a * b_dim;
     s_orow[tid] = (img * p.OHf + a * p.OS + p.cls[ci].ph) * p.OWf + b * p.OS + p.cls[ci].pw;
+  } else if (p.addend_sub && tid < BM) {   // row of the compact (stride-2 sampled) addend, or -1: the output pixel is not one of its samples
+    const int m = m0 + tid;
+    const int mm = m < rows ? m : m0;
+    const int hw = p.OHf * p.OWf, img = mm / hw, rem = mm - img * hw;
+    const int y = rem / p.OWf, x = rem - y * p.OWf;
+    s_orow[tid] = ((y | x) & 1) ? -1 : (img * ((p.OHf + 1) >> 1) + (y >> 1)) * ((p.OWf + 1) >> 1) + (x >> 1);
   }
   unsigned char* Cs = smem + TAP_LDS_BYTES;
 #pragma unroll
@@ -623,7 +629,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (EPI == 6 && WAVES_M * WAVE
       valid[k] = m < rows && (!PIPE || row < bm_step);
       const int orow = simple_rows ? (valid[k] ? m : m0) : s_orow[row];
       goffs[k] = ((size_t)orow * p.Cout + n0 + cj * EPC) * sizeof(T);
-      if constexpr (HAS_ADD) q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+      if constexpr (HAS_ADD) {
+        if (p.addend_sub) {
+          const int ar = s_orow[row];
+          q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] && ar >= 0 ? add_b + ((size_t)ar * p.Cout + n0 + cj * EPC) * sizeof(T) : zp);
+        } else q_ad[k] = *reinterpret_cast<const u32x4_t*>(add_b && valid[k] ? add_b + goffs[k] : zp);
+      }
       if constexpr (HAS_MY) q_my[k] = *reinterpret_cast<const u32x4_t*>(my_b && valid[k] ? my_b + goffs[k] : zp);
       if constexpr (HAS_MB) q_mb[k] = (mb_b && valid[k]) ? (uint32_t)mb_b[goffs[k] >> 4] : 0u;
       if constexpr (HAS_X) {
@@ -839,7 +850,7 @@ static bool pipe_choose(const ConvGemmArgs& a, bool tr, int prof, bool heavy, Pi
   static const int mink = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINK"); return v ? atoi(v) : 1024; }();
   static const int mintiles = [] { const char* v = getenv("MMSKIN_CONV_PIPE_MINTILES"); return v ? atoi(v) : 192; }();
   static const int pin = [] { const char* v = getenv("MMSKIN_CONV_PIPE_TILE"); return v ? atoi(v) : 0; }();
-  if (!on || !a.pipe_ok || a.in2 || prof == 7 || a.ep_mask_out || a.ep_mul || !a.out || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
+  if (!on || !a.pipe_ok || a.in2 || a.addend_sub || prof == 7 || a.ep_mask_out || a.ep_mul || !a.out || a.in_bytes == 0 || a.in_bytes > 0xE0000000ull || (heavy && prof == 1) || a.Cout % 256 != 0 ||
       a.C % 64 != 0 || a.ncls < 1)
     return false;
   if (tr && (heavy || a.addend || a.stat_sum || !a.out_f32)) return false;   // the transformer-residual epilogue's own contract (checked below)
@@ -1021,6 +1032,10 @@ int launch_conv_dgrad(const ConvShape& s, const T* dout, const T* wt_staged, T* 
               "conv_dgrad: epilogue fusion needs a launch that covers every output pixel");
     a.ep_mask_y = fuse->mask_y; a.ep_mask_bits = fuse->mask_bits; a.ep_x = fuse->x; a.ep_x_pitch = fuse->x_pitch; a.ep_scale = fuse->scale; a.ep_shift = fuse->shift;
     a.ep_x2 = fuse->x2;
+    if (fuse->addend_s2) {
+      ARG_CHECK(addend && addend != din && s.kh == 1 && s.kw == 1 && s.stride == 1 && s.pad == 0, "conv_dgrad: a compact stride-2 addend needs a 1x1 / stride 1 launch and its own buffer");
+      a.addend_sub = 2;
+    }
     a.stat_stride = 2 * s.Cin;
     a.stat_sum = fuse->partial; a.stat_sq = fuse->partial + s.Cin;
     if (fuse->x2) { a.stat_b_sum = fuse->partial_b; a.stat_b_sq = fuse->partial_b + s.Cin; }

@@ -656,3 +656,42 @@ def test_eval_forward_reuses_staged_weights_only_while_unchanged():
         assert rel_err(e, d) > 1e-5                                   # the statistics did move
         enc(torch.randn(3, 3, 64, 64, device=DEV)); enc(torch.randn(5, 3, 64, 64, device=DEV))
     assert enc._plan_for(4, 64, 64, x.device) is plan4 and len(enc._plans) == 4
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_compact_downsample_gradient_is_bit_identical(dtype):
+    """Backward of the stride-2 downsample branch: its data gradient as a dense GEMM into a compact buffer, added at the even pixels by
+    conv1's dgrad epilogue (default), against the zero-filled full-resolution form (MMSKIN_DS_COMPACT=0).  Same products, same fp32
+    accumulation, the same single rounding of (acc + addend): every backbone gradient must have the SAME bits.  Odd feature-map sizes
+    (23 x 18 into layer2: ceil(H / 2) samples) and a ragged batch."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import os, sys, torch
+sys.path[:0] = [%r, %r]
+os.environ["MMSKIN_BACKBONE_DTYPE"] = %r
+from gpu_util import DEV
+from models import loadImageModelClassifier as L
+torch.manual_seed(3)
+enc, dim = L.loadModels.loadModelImageEncoder("resnet-50", 512, "unfrozen_weights")
+enc = enc.to(DEV).train()
+g = torch.Generator().manual_seed(4)
+x = torch.randn(3, 3, 90, 70, generator=g).to(DEV)
+y = enc(x)
+w = torch.randn(y.shape, generator=g).to(DEV)
+(y * w).sum().backward()
+torch.cuda.synchronize()
+torch.save({n: p.grad.detach().cpu() for n, p in enc.named_parameters()}, sys.argv[1])
+"""
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for knob in ("1", "0"):
+            f = os.path.join(td, f"g{knob}.pt")
+            r = subprocess.run([sys.executable, "-c", code % (os.path.join(root, "tests"), os.path.join(root, "multimodal-model-skin-lesion-classifier_amd"), dtype), f],
+                               env=dict(os.environ, MMSKIN_DS_COMPACT=knob), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            outs.append(torch.load(f))
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) > 150
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all() and float(outs[0][k].abs().max()) > 0, k
+        assert torch.equal(outs[0][k], outs[1][k]), (k, float((outs[0][k] - outs[1][k]).abs().max()))
