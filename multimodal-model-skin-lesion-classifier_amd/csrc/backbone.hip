@@ -757,7 +757,10 @@ int backward_impl(Plan& p, const float* dfeat, const float* params, unsigned cha
     float* cB = cA + 64; float* cC = cA + 128;
     int nr = 0;
     p.prof.begin(K_BN_BWD, st);
-    rc = stem_pool_bn_bwd_reduce<T>(g, ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
+    // MMSKIN_STEM_SUMS_POOLED=0: the sums from the conv output and the routed gradient (565 MB read instead of 206 MB)
+    static const bool pooled_sums = [] { const char* v = getenv("MMSKIN_STEM_SUMS_POOLED"); return !v || atoi(v) != 0; }();
+    if (pooled_sums) rc = stem_pool_bwd_sums<T>(g, reinterpret_cast<const T*>(ws + p.off_pool), ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
+    else rc = stem_pool_bn_bwd_reduce<T>(g, ws + p.off_idx, x0, c0, c0 + 64, p.N, p.OH0, p.OW0, 64, partial, &nr, st);
     if (!rc) rc = bn_bwd_finalize(partial, nr, 64, (double)u0.rows(), params + u0.g_off, c0 + 128, c0 + 192, grads + u0.g_off,
                                   grads + u0.b_off, cA, cB, cC, reinterpret_cast<double*>(ws + p.off_red), st);
     if (!rc) rc = stem_pool_bn_bwd_apply<T>(g, ws + p.off_idx, x0, c0, c0 + 64, cA, cB, cC, p.N, p.OH0, p.OW0, 64, dx0, st);

@@ -215,7 +215,10 @@ int stem_bwd_op(const float* dy, const float* x, const float* w, const float* ga
   if ((rc = nchw_to_nhwc<T>(dy, N, 64, g.PH, g.PW, s.dpool, st))) return rc;
   // the plans' fused path: max-pool + ReLU + BatchNorm backward on pooled cells, no full-resolution pooled gradient
   int nr = 0;
-  if ((rc = stem_pool_bn_bwd_reduce<T>(s.dpool, s.idx, s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.partial, &nr, st))) return rc;
+  static const bool pooled_sums = [] { const char* v = getenv("MMSKIN_STEM_SUMS_POOLED"); return !v || atoi(v) != 0; }();   // as the ResNet plan
+  if (pooled_sums) rc = stem_pool_bwd_sums<T>(s.dpool, s.pool, s.idx, s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.partial, &nr, st);
+  else rc = stem_pool_bn_bwd_reduce<T>(s.dpool, s.idx, s.x0, s.coef, s.coef + 64, N, g.OH, g.OW, 64, s.partial, &nr, st);
+  if (rc) return rc;
   if ((rc = bn_bwd_finalize(s.partial, nr, 64, (double)rows, gamma, s.coef + 128, s.coef + 192,
                             dgamma, dbeta, s.coef + 256, s.coef + 320, s.coef + 384, s.red, st))) return rc;
   if ((rc = stem_pool_bn_bwd_apply<T>(s.dpool, s.idx, s.x0, s.coef, s.coef + 64, s.coef + 256, s.coef + 320, s.coef + 384, N, g.OH,

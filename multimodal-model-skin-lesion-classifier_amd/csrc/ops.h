@@ -67,6 +67,10 @@ int stem_bn_relu_pool(const T* x, const float* scale, const float* shift, int N,
 // Stem backward without the full-resolution un-pooled gradient: dz = (sum of dpool over the pooling windows whose argmax is (h,w))[c] * (x*scale+shift > 0) is
 // recomputed from the pooled gradient + argmax bytes inside the BatchNorm-backward reduce and apply passes
 // (saves one 411 MB write and two reads of it at batch 256).
+// the same partial sums from the pooled tensors alone (dpool, the pooled forward output ypool): x at a window's argmax is (y - shift) / scale
+template <typename T>
+int stem_pool_bwd_sums(const T* dpool, const T* ypool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N, int H, int W,
+                       int C, float* partial, int* nrows_out, hipStream_t st);
 template <typename T>
 int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N,
                             int H, int W, int C, float* partial, int* nrows_out, hipStream_t st);

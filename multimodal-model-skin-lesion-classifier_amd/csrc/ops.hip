@@ -260,7 +260,7 @@ static unsigned* bn_tickets_for(hipStream_t st) {
   static unsigned* base = nullptr;
   static hipStream_t owner[16];
   static int n = 0;
-  // OFF by default: measured 19.17 vs 17.85 ms per ResNet-50 step (profiles/r04_experiments.txt (12)) -- every block's agent-scope fence
+  // OFF by default: measured 19.17 vs 17.85 ms per ResNet-50 step (profiles/r04_experiments.txt (11)) -- every block's agent-scope fence
   // writes back / invalidates its XCD's whole L2 while the other stream's kernels are filling it; 40 such launches cost 1.3 ms
   static const int on = [] { const char* e = getenv("MMSKIN_BN_FUSED_STAGES"); return e ? atoi(e) : 0; }();
   if (!on) return nullptr;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void bn_bwd_coeffs(int c, double s1, double s2, doubl
 }
 // CB columns x RL row lanes per block.  CB = 16 (256 threads, 4 KB of LDS) is the backward pass's form: a block that small fits on a CU
 // beside a weight-gradient ring workgroup of the other stream (208 VGPRs x 8 waves, 121 - 132 KB of LDS), where the 1024-thread form
-// waited for a ring workgroup to retire -- i.e. for the whole weight-gradient launch (profiles/r04_experiments.txt (9)).
+// waited for a ring workgroup to retire -- i.e. for the whole weight-gradient launch (profiles/r04_experiments.txt (8)).
 template <typename IN, int RL = 4, int CB = 64>
 __global__ __launch_bounds__(CB * RL) void bn_bwd_finalize_kernel(const IN* __restrict__ partial, int nrows, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -976,6 +976,77 @@ int stem_pool_bn_bwd_reduce(const T* dpool, const uint8_t* idx, const T* x, cons
   *nrows_out = g.gx;
   return MMSKIN_OK;
 }
+// The same two sums from the POOLED side: every pooled cell hands its gradient to exactly one conv cell (its argmax), that cell's ReLU
+// is open exactly when the pooled value is positive, and its pre-BatchNorm value follows from the pooled value, x = (y - shift) / scale
+// (y is the rounded relu(scale x + shift): the reconstruction differs from the stored x by y's rounding over scale, the size of x's own
+// rounding).  So  sum dz = sum_pooled [y > 0] dpool,  sum dz x = sum_pooled [y > 0] dpool x(y)  -- one pass over the two pooled tensors
+// (206 MB at batch 256) instead of the conv output + pooled gradient + argmax bytes (565 MB, 12 loads and two divisions per cell).
+// A channel whose scale is exactly zero (gamma = 0) cannot be inverted: it reads x at the argmax the forward recorded (never taken otherwise).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_bwd_sums_kernel(const T* __restrict__ dpool, const T* __restrict__ ypool, const uint8_t* __restrict__ idx,
+                                                                const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                int H, int W, int PH, int PW, size_t cells, int C, ColGeom g, float* partial) {
+  constexpr int EPC = DT<T>::EPC;
+  __shared__ float red[2 * 256 * EPC];
+  const int cx = threadIdx.x % g.CW, ry = threadIdx.x / g.CW;
+  const int col = blockIdx.y * g.CW + cx;
+  float acc[2][EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+  if (ry < g.RL && col < g.CPR) {
+    size_t r_end = (size_t)(blockIdx.x + 1) * g.RB;
+    if (r_end > cells) r_end = cells;
+    const int c0 = col * EPC;
+    float inv[EPC], sh[EPC];
+    bool degenerate = false;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float sc = scale[c0 + e];
+      sh[e] = shift[c0 + e];
+      inv[e] = sc != 0.f ? 1.f / sc : 0.f;
+      degenerate |= sc == 0.f;
+    }
+    for (size_t r = (size_t)blockIdx.x * g.RB + ry; r < r_end; r += g.RL) {
+      const size_t off = (r * g.CPR + col) * EPC;
+      Chunk<T> dz, yv;
+      dz.load(dpool + off);
+      yv.load(ypool + off);
+      float xr[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xr[e] = (yv.v[e] - sh[e]) * inv[e];
+      if (degenerate) {
+        const unsigned r32 = (unsigned)r, t = r32 / (unsigned)PW;
+        const int pw = (int)(r32 - t * (unsigned)PW);
+        const unsigned n = t / (unsigned)PH;
+        const int ph = (int)(t - n * (unsigned)PH);
+        for (int e = 0; e < EPC; ++e)
+          if (inv[e] == 0.f) {
+            const int tap = idx[off + e], hh = 2 * ph - 1 + tap / 3, ww = 2 * pw - 1 + tap % 3;
+            xr[e] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? to_f32(x[(((size_t)n * H + hh) * W + ww) * C + c0 + e]) : 0.f;
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float v = yv.v[e] > 0.f ? dz.v[e] : 0.f;
+        acc[0][e] += v; acc[1][e] += v * xr[e];
+      }
+    }
+  }
+  block_col_reduce<EPC, 2>(acc, cx, ry, g.CW, g.RL, col, g.CPR, C, partial, red);
+}
+template <typename T>
+int stem_pool_bwd_sums(const T* dpool, const T* ypool, const uint8_t* idx, const T* x, const float* scale, const float* shift, int N, int H, int W,
+                       int C, float* partial, int* nrows_out, hipStream_t st) {
+  ARG_CHECK(C % DT<T>::EPC == 0, "stem_pool_bwd_sums: C=%d", C);
+  const int PH = (H + 2 - 3) / 2 + 1, PW = (W + 2 - 3) / 2 + 1;
+  const size_t cells = (size_t)N * PH * PW;
+  ARG_CHECK(cells < ((size_t)1 << 32), "stem_pool_bwd_sums: %zu cells", cells);
+  ColGeom g = col_geom(cells, C, DT<T>::EPC);
+  hipLaunchKernelGGL(stem_pool_bwd_sums_kernel<T>, dim3(g.gx, g.gy), dim3(256), 0, st, dpool, ypool, idx, x, scale, shift, H, W, PH, PW, cells, C, g, partial);
+  HIP_CHECK_RET(hipGetLastError());
+  *nrows_out = g.gx;
+  return MMSKIN_OK;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pool_bn_bwd_apply_kernel(
     const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x, const float* __restrict__ scale,
@@ -1213,6 +1284,7 @@ int nhwc_to_nchw(const T* src, int N, int C, int H, int W, float* dst, hipStream
   template int stem_pack_u8<T>(const uint8_t*, int, int, int, int, int, const float*, T*, hipStream_t);        \
   template int stem_bn_relu_pool<T>(const T*, const float*, const float*, int, int, int, int, T*, uint8_t*, hipStream_t); \
   template int stem_pool_bn_bwd_reduce<T>(const T*, const uint8_t*, const T*, const float*, const float*, int, int, int, int, float*, int*, hipStream_t); \
+  template int stem_pool_bwd_sums<T>(const T*, const T*, const uint8_t*, const T*, const float*, const float*, int, int, int, int, float*, int*, hipStream_t); \
   template int stem_pool_bn_bwd_apply<T>(const T*, const uint8_t*, const T*, const float*, const float*, const float*, const float*, const float*, int, int, int, int, T*, hipStream_t); \
   template int avgpool_fwd<T>(const T*, int, int, int, float*, hipStream_t);                                    \
   template int avgpool_bwd<T>(const float*, int, int, int, T*, hipStream_t);                                    \

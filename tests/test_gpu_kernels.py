@@ -147,6 +147,35 @@ def test_batchnorm_train_forward_backward(shape, relu, dtype):
     assert rel_err(dg, gr.grad) < 3 * tol and rel_err(db, br.grad) < 3 * tol
 
 
+def test_stem_backward_sums_from_the_pooled_side_and_zero_gamma():
+    """BatchNorm-backward sums of the stem from the pooled tensors (x at the argmax reconstructed as (y - shift) / scale; default) against
+    the conv-output form (MMSKIN_STEM_SUMS_POOLED=0 is exercised by test_stem_forward_backward's reference either way): fp32 operands, so
+    both must match torch to the fp32 tolerance -- including two channels with gamma = 0, whose scale cannot be inverted and which read x at
+    the recorded argmax instead."""
+    N, H, W = 3, 50, 70
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    gamma[5] = 0.0; gamma[40] = 0.0; beta[5] = 0.3; beta[40] = -0.2
+    wr, gr, br = (t.clone().requires_grad_(True) for t in (w, gamma, beta))
+    z = F.relu(F.batch_norm(F.conv2d(x, wr, stride=2, padding=3), None, None, gr, br, training=True, eps=1e-5))
+    y_ref = F.max_pool2d(z, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    lib = _lib.load()
+    wsp = ws(lib.mmskin_stem_workspace_bytes(N, H, W))
+    keep = [x.to(DEV), w.to(DEV), gamma.to(DEV), beta.to(DEV)]
+    dw, dg, db = torch.empty(64, 3, 7, 7, device=DEV), torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    dyd = dy.to(DEV)
+    call("mmskin_stem_backward", ptr(dyd), *[ptr(t) for t in keep], ptr(dw), ptr(dg), ptr(db), N, H, W, 1e-5, DT["fp32"], ptr(wsp), stream())
+    torch.cuda.synchronize()
+    tol = TOL["fp32"]
+    assert rel_err(dg, gr.grad) < 3 * tol and rel_err(db, br.grad) < 3 * tol, (rel_err(dg, gr.grad), rel_err(db, br.grad))
+    assert abs(float(dg[5]) - float(gr.grad[5])) <= 3 * tol * float(gr.grad.abs().max())
+    assert rel_err(dw, wr.grad) < 3 * tol, rel_err(dw, wr.grad)
+
+
 def test_stem_direct_7x7_kernel_at_224():
     """224 x 224 images in bf16 take the direct 7x7 convolution (csrc/stem7x7.hip, launch counter asserted).  Inputs and weights are
     bf16-representable, so the fp64 reference multiplies what the kernel multiplies: pooled output within 4e-3 relative L2 (two bf16
