@@ -472,7 +472,7 @@ def main():
         # frac = the PRODUCTION figure (the dominant kernel's launches as they run in the timed step, beside the weight-gradient stream:
         # committed un-instrumented trace of exactly these sources) when one is committed, else the live isolated one (side stream off)
         frac_live = round(achieved / peak, 4)
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (implicit-GEMM conv fwd + dgrad)",
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel + conv3x3_c64_kernel + stem7x7_kernel (convolution forward + dgrad launches)",
                     "achieved": round(achieved if frac_production is None else frac_production * peak, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": frac_live if frac_production is None else frac_production,
                     "frac_basis": "isolated (live HIP events, side stream off)" if frac_production is None else "production (committed kernel trace of these sources)",

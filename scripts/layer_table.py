@@ -22,13 +22,16 @@ stem = ("stem", dict(Mo=N * 112 * 112, Mi=N * 224 * 224, Cin=3, Cout=64, taps=49
 fwd = [stem]
 import os
 FWD2P = os.environ.get("MMSKIN_FWD2P", "1") != "0" and os.environ.get("MMSKIN_ABN", "1") != "0"
+FWDG = os.environ.get("MMSKIN_FWDG", "1") != "0"
 for u, ds in blocks:
     if ds: fwd.append(ds)
-    fwd += u
-    # two-pass forward (backbone.hip): conv3 of a layer1 / layer2 block without a downsample branch runs twice -- statistics only, then
-    # conv + BatchNorm + residual + ReLU in the epilogue (the "c3" row is the statistics pass, "c3+bn" the second one)
+    # two-pass forward (backbone.hip): conv3 of a layer1 / layer2 block without a downsample branch is one conv launch with BatchNorm +
+    # residual + ReLU in its epilogue ("c3+bn"); its statistics come from the Gram matrix of its input (a ring-kernel launch, not listed
+    # here).  MMSKIN_FWDG=0: a statistics-only pass of the convolution first (the "c3" row).
     if FWD2P and not ds and u[2][1]["Cin"] <= 128:
-        fwd.append((u[2][0] + "+bn", u[2][1]))
+        fwd += u[:2] + ([u[2]] if not FWDG else []) + [(u[2][0] + "+bn", u[2][1])]
+    else:
+        fwd += u
 bwd = []   # per block, last to first: conv3, conv2, (downsample), conv1 -- the plan's dgrad order
 for u, ds in reversed(blocks):
     bwd += [u[2], u[1]] + ([ds] if ds else []) + [u[0]]
@@ -38,7 +41,7 @@ def bytes_fwd(d):   # read the input once (a strided 1x1 reads a quarter of the 
     return 2.0 * (mi * d["Cin"] + d["Mo"] * d["Cout"] + d["Cout"] * d["Cin"] * d["taps"])
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-def is_conv(r): return "conv_gemm_kernel" in r["Kernel_Name"] or "conv3x3_c64_kernel" in r["Kernel_Name"]
+def is_conv(r): return any(k in r["Kernel_Name"] for k in ("conv_gemm_kernel", "conv3x3_c64_kernel", "stem7x7_kernel"))
 conv_all = [r for r in rows if is_conv(r)]
 # The forward downsample convolutions run on the side stream (another HSA queue) beside conv1..conv3 of their block, so start-time
 # order interleaves them arbitrarily: split the dispatches by queue -- the main queue carries stem, conv1..3 of every block and every
@@ -72,7 +75,7 @@ for i, ((name, d), r) in enumerate(zip(fwd + bwd, conv)):
     us = dur(r); tot[kind] += us
     fl = flops(d); hb = bytes_fwd(d) / 6.3e12 * 1e6; mf = fl / 2.5e15 * 1e6
     M, Nn, K = (d["Mo"], d["Cout"], d["Cin"] * d["taps"]) if kind == "F" else (d["Mi"], d["Cin"], d["Cout"] * d["taps"])
-    kn = "layer-1 3x3" if "conv3x3_c64" in r["Kernel_Name"] else ("pipelined" if int(r["Workgroup_Size_X"]) == 512 else "128-row")
+    kn = "direct 7x7" if "stem7x7" in r["Kernel_Name"] else "layer-1 3x3" if "conv3x3_c64" in r["Kernel_Name"] else ("pipelined" if int(r["Workgroup_Size_X"]) == 512 else "128-row")
     print(f"{kind} {name:10s} {M:8d} {Nn:5d} {K:5d} {us:8.1f} {fl / us / 1e6:7.0f} {hb:8.1f} {mf:8.1f} {us / max(hb, mf):6.2f}  {kn} x{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X'])}")
 print(f"forward {tot['F'] / 1e3:.3f} ms, dgrad {tot['D'] / 1e3:.3f} ms per step (production: beside the side stream's weight-gradient GEMMs)")
 wg = [r for r in rows if "wgrad" in r["Kernel_Name"] and "reduce" not in r["Kernel_Name"] and "unpack" not in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"]]

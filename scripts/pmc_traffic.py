@@ -19,8 +19,8 @@ from bench import source_hash  # noqa: E402
 
 
 def dom(name):
-    """the dominant class: the implicit-GEMM conv forward + dgrad launches (conv_gemm.hip: 128-row and pipelined kernels; conv3x3_c64.hip)"""
-    return "conv_gemm_kernel" in name or "conv3x3_c64_kernel" in name
+    """the dominant class: the implicit-GEMM conv forward + dgrad launches (conv_gemm.hip: 128-row and pipelined kernels; conv3x3_c64.hip; stem7x7.hip)"""
+    return "conv_gemm_kernel" in name or "conv3x3_c64_kernel" in name or "stem7x7_kernel" in name
 
 
 def per_step_kib(directory, counter):
@@ -37,7 +37,7 @@ fetch_kib, n1 = per_step_kib(sys.argv[1], "FETCH_SIZE")
 write_kib, n2 = per_step_kib(sys.argv[2], "WRITE_SIZE")
 assert n1 == n2, (n1, n2)
 hbm = (2.0 * fetch_kib + write_kib) * 1024.0
-out = {"kernel": f"conv_gemm_kernel + conv3x3_c64_kernel ({n1} launches per step: forward + dgrad)",
+out = {"kernel": f"conv_gemm_kernel + conv3x3_c64_kernel + stem7x7_kernel ({n1} launches per step: forward + dgrad)",
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, python3 bench.py --steps 1 --warmup 1",
        "fetch_size_kib_per_step": fetch_kib, "write_size_kib_per_step": write_kib,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact",

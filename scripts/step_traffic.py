@@ -14,7 +14,7 @@ def load(directory, counter):
 
 
 def klass(n):
-    for key, name in (("wgrad", "weight gradient (+ slab reduction)"), ("gram_reduce", "weight gradient (+ slab reduction)"), ("abn_", "algebraic BatchNorm backward (fold / fix-up)"), ("conv_gemm_kernel", "conv forward + dgrad"), ("conv3x3_c64", "conv forward + dgrad"),
+    for key, name in (("wgrad", "weight gradient (+ slab reduction)"), ("gram_reduce", "weight gradient (+ slab reduction)"), ("abn_", "algebraic BatchNorm backward (fold / fix-up)"), ("conv_gemm_kernel", "conv forward + dgrad"), ("conv3x3_c64", "conv forward + dgrad"), ("stem7x7", "conv forward + dgrad"), ("adam_step", "Adam"), ("gram_stats", "BatchNorm reductions / finalize"),
                       ("bn_bwd_apply", "BatchNorm backward apply"), ("bn_apply", "BatchNorm forward apply"), ("stem_", "stem (pack / pool / BatchNorm)"),
                       ("bn_", "BatchNorm reductions / finalize"), ("partial_reduce", "BatchNorm reductions / finalize"), ("stage_weights", "weight staging"),
                       ("multi_tensor_apply", "Adam"), ("avgpool", "pooling"), ("parity_zero_fill", "conv forward + dgrad")):
