@@ -54,27 +54,14 @@ __global__ void split_reduce_kernel(const float* __restrict__ part, float* __res
 #define LG_EPT (LG_T * LG_BK / 256)   // elements per thread and operand
 template <bool KC> __device__ __forceinline__ int lg_idx(int row, int k) { return KC ? row * LG_PK + k : k * LG_PM + row; }
 
+constexpr int LG_LDS = LG_BK * LG_PM > LG_T * LG_PK ? LG_BK * LG_PM : LG_T * LG_PK;   // floats per operand tile
+// one 32 x 32 output tile (bx, by) of C = A B^T (+ bias, ReLU); As / Bs: LG_LDS floats each
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                       float* __restrict__ c, const float* __restrict__ bias, int M,
-                                                       int N, int K, int64_t sam, int64_t sak, int64_t sbn,
-                                                       int64_t sbk, int64_t ldc, int relu, int kchunk, int64_t sab,
-                                                       int64_t sbb, int64_t scb) {
-  __shared__ float As[LG_BK * LG_PM > LG_T * LG_PK ? LG_BK * LG_PM : LG_T * LG_PK];
-  __shared__ float Bs[LG_BK * LG_PM > LG_T * LG_PK ? LG_BK * LG_PM : LG_T * LG_PK];
-  if (kchunk < 0) {   // batched: blockIdx.z = batch index (no split-K)
-    a += (int64_t)blockIdx.z * sab; b += (int64_t)blockIdx.z * sbb; c += (int64_t)blockIdx.z * scb;
-  }
-  // split-K (kchunk > 0): slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and writes its own M x ldc
-  // partial matrix; the caller sums the slices.  Used by the weight-gradient GEMMs whose K is batch*tokens.
-  if (kchunk > 0) {
-    const int kb = blockIdx.z * kchunk;
-    a += (int64_t)kb * sak; b += (int64_t)kb * sbk;
-    c += (int64_t)blockIdx.z * M * ldc;
-    K = min(kchunk, K - kb);
-  }
+__device__ __forceinline__ void gemm_f32_tile(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                                              const float* __restrict__ bias, int M, int N, int K, int64_t sam, int64_t sak, int64_t sbn,
+                                              int64_t sbk, int64_t ldc, int relu, int bx, int by, float* As, float* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.y * LG_T, n0 = blockIdx.x * LG_T;
+  const int m0 = by * LG_T, n0 = bx * LG_T;
   const int wm = wid >> 1, wn = wid & 1;
   f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float ra[LG_EPT], rb[LG_EPT];
@@ -121,6 +108,63 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         c[(int64_t)m * ldc + n] = v;
       }
     }
+  }
+}
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ c, const float* __restrict__ bias, int M,
+                                                       int N, int K, int64_t sam, int64_t sak, int64_t sbn,
+                                                       int64_t sbk, int64_t ldc, int relu, int kchunk, int64_t sab,
+                                                       int64_t sbb, int64_t scb) {
+  __shared__ float As[LG_LDS];
+  __shared__ float Bs[LG_LDS];
+  if (kchunk < 0) {   // batched: blockIdx.z = batch index (no split-K)
+    a += (int64_t)blockIdx.z * sab; b += (int64_t)blockIdx.z * sbb; c += (int64_t)blockIdx.z * scb;
+  }
+  // split-K (kchunk > 0): slice blockIdx.z covers k in [z*kchunk, (z+1)*kchunk) and writes its own M x ldc
+  // partial matrix; the caller sums the slices.  Used by the weight-gradient GEMMs whose K is batch*tokens.
+  if (kchunk > 0) {
+    const int kb = blockIdx.z * kchunk;
+    a += (int64_t)kb * sak; b += (int64_t)kb * sbk;
+    c += (int64_t)blockIdx.z * M * ldc;
+    K = min(kchunk, K - kb);
+  }
+  gemm_f32_tile<A_KC, B_KC>(a, b, c, bias, M, N, K, sam, sak, sbn, sbk, ldc, relu, blockIdx.x, blockIdx.y, As, Bs);
+}
+// Backward of a small Linear (M = batch rows) in ONE launch: the tiles of dx = g w, the tiles of dw = g^T x and the column sums db = sum_m g,
+// selected by block index (three dependent-free launches of 5 - 11 us each were 4.5 us of launch latency apiece: 16 Linear layers per head step)
+__global__ __launch_bounds__(256) void linear_bwd_small_kernel(const float* __restrict__ g, const float* __restrict__ w, const float* __restrict__ x,
+                                                               float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int K,
+                                                               int N, int nx_dx, int n_dx, int nx_dw, int n_dw) {
+  __shared__ float As[LG_LDS];
+  __shared__ float Bs[LG_LDS];
+  int b = blockIdx.x;
+  if (b < n_dx) {   // dx[m][k] = sum_n g[m][n] w[n][k]
+    gemm_f32_tile<true, false>(g, w, dx, nullptr, M, K, N, N, 1, 1, K, K, 0, b % nx_dx, b / nx_dx, As, Bs);
+    return;
+  }
+  b -= n_dx;
+  if (b < n_dw) {   // dw[n][k] = sum_m g[m][n] x[m][k]
+    gemm_f32_tile<false, false>(g, x, dw, nullptr, N, K, M, 1, N, 1, K, K, 0, b % nx_dw, b / nx_dw, As, Bs);
+    return;
+  }
+  b -= n_dw;        // db: 32 columns x 8 row lanes, four independent sums per lane
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, n = b * 32 + cx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (n < N) {
+    int m = ry;
+    for (; m + 24 < M; m += 32) {
+      s0 += g[(int64_t)m * N + n]; s1 += g[(int64_t)(m + 8) * N + n]; s2 += g[(int64_t)(m + 16) * N + n]; s3 += g[(int64_t)(m + 24) * N + n];
+    }
+    for (; m < M; m += 8) s0 += g[(int64_t)m * N + n];
+  }
+  As[ry * 32 + cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += As[i * 32 + cx];
+    db[n] = t;
   }
 }
 
@@ -1654,6 +1698,16 @@ static int linear_backward_impl(const float* dy, const float* x, const float* w,
       if ((rc = launch_conv_wgrad<float>(s, g, x, reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scratch) + wt_bytes), dw, st))) return rc;
     }
     if (db && (rc = colsum(g, db, M, N, st))) return rc;
+    return MMSKIN_OK;
+  }
+  static const bool one_launch = [] { const char* v = getenv("MMSKIN_LINEAR_BWD_ONE"); return !v || atoi(v) != 0; }();
+  if (one_launch && M < 4096 && (dx || dw || db)) {   // (a longer contraction takes the split-K form of the separate launches)
+    ARG_CHECK((!dx || w) && (!dw || x), "linear_backward: w / x required");
+    const int nx_dx = ceil_div(K, LG_T), n_dx = dx ? nx_dx * ceil_div(M, LG_T) : 0;
+    const int nx_dw = ceil_div(K, LG_T), n_dw = dw ? nx_dw * ceil_div(N, LG_T) : 0;
+    const int n_db = db ? ceil_div(N, 32) : 0;
+    hipLaunchKernelGGL(linear_bwd_small_kernel, dim3(n_dx + n_dw + n_db), dim3(256), 0, st, g, w, x, dx, dw, db, M, K, N, nx_dx, n_dx, nx_dw, n_dw);
+    HIP_CHECK_RET(hipGetLastError());
     return MMSKIN_OK;
   }
   if (dx) {  // dx[m][k] = sum_n g[m][n] * w[n][k]
