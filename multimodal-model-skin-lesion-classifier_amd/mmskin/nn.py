@@ -8,7 +8,11 @@ forward is overridden to call the C ABI through mmskin.ops.
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
+
+_MHA_ROWS = os.environ.get("MMSKIN_MHA_ROWS", "1") != "0"
 
 
 class HipLinear(nn.Linear):
@@ -69,7 +73,10 @@ class HipMultiheadAttention(nn.MultiheadAttention):
         Lq, B, _ = query.shape
         Lk = key.shape[0]
         if Lk == 1:
-            v = ops.linear(value.reshape(B, D), W[2 * D:], Bv[2 * D:] if Bv is not None else None)
+            if _MHA_ROWS:
+                v = ops.linear_rows(value.reshape(B, D), W, Bv, 2 * D, 3 * D)
+            else:   # autograd's slice backward: two fills + two copies per call (A/B: MMSKIN_MHA_ROWS=0)
+                v = ops.linear(value.reshape(B, D), W[2 * D:], Bv[2 * D:] if Bv is not None else None)
             o = ops.linear(v, self.out_proj.weight, self.out_proj.bias).reshape(1, B, D)
             if Lq != 1:
                 o = o.expand(Lq, B, D)

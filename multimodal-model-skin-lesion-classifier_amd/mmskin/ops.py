@@ -80,6 +80,53 @@ class LinearFn(torch.autograd.Function):
         return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None, dres
 
 
+class LinearRowsFn(torch.autograd.Function):
+    """y = x @ w[r0:r1].T + b[r0:r1] for a ROW BLOCK of a stacked parameter (the value projection of nn.MultiheadAttention's
+    in_proj_weight / in_proj_bias when a single key makes the q / k projections dead, multimodalIntraInterModal.py:190-197).  The
+    backward hands autograd the gradients of the WHOLE parameters: one zero fill for both, the row block written in place by the
+    Linear-backward launch -- autograd's own slice backward costs two fills and two copies per call (16 launches per head step)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, r0, r1):
+        _need_gpu(x, "linear_rows")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        w = _f32c(w)
+        b = _f32c(b) if b is not None else None
+        M, K = x2.shape
+        N = r1 - r0
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        call("mmskin_linear_forward", ptr(x2), w.data_ptr() + 4 * r0 * K, (b.data_ptr() + 4 * r0) if b is not None else None, ptr(y),
+             M, K, N, 0, stream())
+        ctx.save_for_backward(x2 if ctx.needs_input_grad[1] else None, w)
+        ctx.rows, ctx.mk, ctx.xshape = (r0, r1), (M, K), x.shape
+        ctx.bias = None if b is None else (b.shape, b.dtype)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w = ctx.saved_tensors
+        (r0, r1), (M, K) = ctx.rows, ctx.mk
+        N = r1 - r0
+        dy2 = _f32c(dy).reshape(M, N)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.bias is not None and ctx.needs_input_grad[2]
+        dx = torch.empty((M, K), device=dy.device, dtype=torch.float32) if need_x else None
+        nw, nb = (w.numel() if need_w else 0), (ctx.bias[0].numel() if need_b else 0)
+        flat = torch.zeros(nw + nb, device=dy.device, dtype=torch.float32) if nw + nb else None
+        dw = flat[:nw].view_as(w) if need_w else None
+        db = flat[nw:].view(ctx.bias[0]) if need_b else None
+        call("mmskin_linear_backward", ptr(dy2), ptr(xs), w.data_ptr() + 4 * r0 * K, None, None, ptr(dx),
+             (dw.data_ptr() + 4 * r0 * K) if need_w else None, (db.data_ptr() + 4 * r0) if need_b else None, M, K, N, stream())
+        return (dx.reshape(ctx.xshape) if need_x else None), dw, db, None, None
+
+
+def linear_rows(x, w, b, r0, r1):
+    """nn.functional.linear(x, w[r0:r1], b[r0:r1]) with the gradients of w / b produced whole (exact zeros outside the row block)."""
+    if x.dtype != torch.float32 or not x.is_cuda:
+        return linear(x, w[r0:r1], b[r0:r1] if b is not None else None)
+    return LinearRowsFn.apply(x, w, b, r0, r1)
+
+
 def lane_dtype(x, module=None, *tensors):
     """torch.bfloat16 when the INFERENCE LANE applies to a layer -- bf16-operand mode and no gradient flows through it (input,
     the module's parameters and `tensors` all without grad, or grad mode off): activations are then handed between the layer's
