@@ -111,8 +111,12 @@ int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStrea
 // narrowest tensor, instead of a statistics-only pass of the convolution):
 //     sum_m x[m][o] = sum_k W[o][k] colsum[k]            sum_m x[m][o]^2 = w_o^T (y^T y) w_o
 // W as multiplied (bf16-rounded); sums in double, stored as the one-row fp32 statistics table bn_finalize reads.  grid = C4 blocks, Cw threads.
+struct GramBn {   // stat_sum == nullptr: finalize here -- the BatchNorm coefficients of ops.hip bn_finalize straight from the two sums
+  double count; const float* gamma; const float* beta; float eps, momentum;
+  float* running_mean; float* running_var; float* scale; float* shift; float* save_mean; float* save_invstd;
+};
 __global__ __launch_bounds__(256) void gram_stats_kernel(const float* __restrict__ Gm, const float* __restrict__ colsum, const float* __restrict__ W,
-                                                         int Cw, float* __restrict__ stat_sum, float* __restrict__ stat_sq) {
+                                                         int Cw, float* __restrict__ stat_sum, float* __restrict__ stat_sq, const GramBn bn) {
   __shared__ float wrow[256];
   __shared__ double red[2][256];
   const int o = blockIdx.x, k = threadIdx.x;
@@ -131,11 +135,26 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const float* __restrict
     if (k < s) { red[0][k] += red[0][k + s]; red[1][k] += red[1][k + s]; }
     __syncthreads();
   }
-  if (k == 0) { stat_sum[o] = (float)red[0][0]; stat_sq[o] = (float)red[1][0]; }
+  if (k == 0) {
+    if (stat_sum) { stat_sum[o] = (float)red[0][0]; stat_sq[o] = (float)red[1][0]; }
+    else   // (the sums go through fp32 exactly as the statistics table would carry them)
+      bn_fwd_coeffs(o, (double)(float)red[0][0], (double)(float)red[1][0], bn.count, bn.gamma, bn.beta, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.scale,
+                    bn.shift, bn.save_mean, bn.save_invstd);
+  }
 }
 int gram_stats(const float* gram, const float* colsum, const float* W, int C4, int Cw, float* stat_sum, float* stat_sq, hipStream_t st) {
   ARG_CHECK(Cw == 64 || Cw == 128 || Cw == 256, "gram_stats: Cw=%d", Cw);
-  hipLaunchKernelGGL(gram_stats_kernel, dim3(C4), dim3(Cw), 0, st, gram, colsum, W, Cw, stat_sum, stat_sq);
+  hipLaunchKernelGGL(gram_stats_kernel, dim3(C4), dim3(Cw), 0, st, gram, colsum, W, Cw, stat_sum, stat_sq, GramBn{});
+  HIP_CHECK_RET(hipGetLastError());
+  return MMSKIN_OK;
+}
+// ... and the BatchNorm finalize in the same launch (training forward of the two-pass units: one dependent launch less per block)
+int gram_stats_finalize(const float* gram, const float* colsum, const float* W, int C4, int Cw, double count, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                        hipStream_t st) {
+  ARG_CHECK(Cw == 64 || Cw == 128 || Cw == 256, "gram_stats_finalize: Cw=%d", Cw);
+  GramBn bn = {count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd};
+  hipLaunchKernelGGL(gram_stats_kernel, dim3(C4), dim3(Cw), 0, st, gram, colsum, W, Cw, (float*)nullptr, (float*)nullptr, bn);
   HIP_CHECK_RET(hipGetLastError());
   return MMSKIN_OK;
 }

@@ -429,15 +429,18 @@ int forward_impl(Plan& p, const void* image, const float* norm6, const float* pa
           float* gcs = gm + (size_t)128 * u.s.Cin;
           PROF(K_BN_FWD, 0.0, (double)u.rows() * u.s.Cin * sizeof(T),
                launch_wgrad_gram(u.s.N, u.s.OH(), u.s.OW(), u.s.Cin, u.s.Cout, nullptr, cur, reinterpret_cast<float*>(ws + p.off_abn_slab2), gm, gcs, st, 2));
-          if ((rc = gram_stats(gm, gcs, params + u.w_off, u.s.Cout, u.s.Cin, stat_sum, stat_sq, st))) return rc;
-          nrows_u = 1;
+          float* cf = reinterpret_cast<float*>(ws + u.coef_off);
+          const int Cq = u.s.Cout;
+          PROF(K_BN_FWD, 0.0, 0.0, gram_stats_finalize(gm, gcs, params + u.w_off, Cq, u.s.Cin, (double)u.rows(), params + u.g_off, params + u.b_off, eps, mom,
+                                                       buffers + u.rm_off, buffers + u.rv_off, cf, cf + Cq, cf + 2 * Cq, cf + 3 * Cq, st));
+          nrows_u = -1;   // coefficients done
         }
       } else {
         PROF(K_CONV_FWD, conv_flops(u.s), conv_bytes(u.s, sizeof(T)),
              launch_conv_fwd<T>(u.s, cur, wf + u.wf_off, two_pass ? (T*)nullptr : x, training ? stat_sum : nullptr,
                                 training ? stat_sq : nullptr, st, nullptr, &nrows_u));
       }
-      if ((rc = bn_coeffs(u, nrows_u))) return rc;
+      if (nrows_u >= 0 && (rc = bn_coeffs(u, nrows_u))) return rc;
       float* coef = reinterpret_cast<float*>(ws + u.coef_off);
       const int C = u.s.Cout;
       if (two_pass) {

@@ -222,4 +222,7 @@ int abn_wgrad_finalize(const float* S, const float* colsum, const float* W, cons
                        const float* gram = nullptr);   // gram: y^T y kept from the forward pass (else the rows behind S's C4 main rows)
 // statistics (sum, sum of squares per output channel, one-row table) of x = y W^T from gram = y^T y [Cw][Cw] and colsum(y)
 int gram_stats(const float* gram, const float* colsum, const float* W, int C4, int Cw, float* stat_sum, float* stat_sq, hipStream_t st);
+int gram_stats_finalize(const float* gram, const float* colsum, const float* W, int C4, int Cw, double count, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
+                        hipStream_t st);   // ... with bn_finalize's coefficients and running statistics from the same launch
 int abn_sgx(const float* S, const float* W, int C4, int Cw, float* sgx, hipStream_t st);

@@ -5,6 +5,27 @@
 #include "common.h"
 
 // ---- BatchNorm forward
+#ifdef __HIPCC__
+// channel c's training-mode BatchNorm coefficients from its sum and sum of squares (double), running statistics updated
+__device__ __forceinline__ void bn_fwd_coeffs(int c, double s, double q, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                              float* save_mean, float* save_invstd) {
+  double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
+  if (running_mean) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+#endif
 // Reduce conv-epilogue partials [nrows][C] -> batch mean/var -> scale/shift (+ running stats).
 int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, double count,
                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,

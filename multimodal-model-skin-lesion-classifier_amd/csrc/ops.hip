@@ -167,26 +167,6 @@ static inline int bn_single_stage_rows() {
 }
 
 // ------------------------------------------------------------------ BN forward
-// channel c's training-mode BatchNorm coefficients from its sum and sum of squares (double), running statistics updated
-__device__ __forceinline__ void bn_fwd_coeffs(int c, double s, double q, double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                              float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                              float* save_mean, float* save_invstd) {
-  double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  float sc = g * invstd;
-  scale[c] = sc;
-  shift[c] = b - (float)mean * sc;
-  if (save_mean) { save_mean[c] = (float)mean; save_invstd[c] = invstd; }
-  if (running_mean) {
-    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 // ---- both reduction stages of a large statistics table in ONE launch.  grid (ceil(C / 64), G) x 512 threads: block (x, g) sums its row
 // group of the two tables for 64 columns into scratch[t][g][c] (double), takes a ticket for its column block, and the block that draws
 // the last one sums the G scratch rows IN ROW ORDER (deterministic whichever block it is) and finalizes.  Meant to save the second launch of
