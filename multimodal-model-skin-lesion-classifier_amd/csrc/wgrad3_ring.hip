@@ -297,7 +297,10 @@ static bool wgrad3_ring_plan_(const ConvShape& s, Wgrad3RingPlan& pl) {
   a.R = R; a.spi = ceil_div(s.H, R);
   a.W2p = W2p; a.yrows = (R + 2) * W2p;
   a.total_stages = s.N * a.spi;
-  pl.wob = (s.Cout % 128 == 0) ? 2 : 1;
+  // MMSKIN_WGRAD3_WOB=1: two pixel groups on a 64-cout tile for every layer (half the slab bytes per workgroup, the window staged per group)
+  static const int wob_env = w3r_env("MMSKIN_WGRAD3_WOB", 0);
+  pl.wob = wob_env ? wob_env : ((s.Cout % 128 == 0) ? 2 : 1);
+  if (s.Cout % 128) pl.wob = 1;
   pl.g = 2 / pl.wob;
   pl.nyw = ceil_div(pl.g * (a.yrows / 8), 8);
   a.nblk_o = s.Cout / (64 * pl.wob); a.nblk_c = s.Cin / 64;
