@@ -167,95 +167,6 @@ static inline int bn_single_stage_rows() {
 }
 
 // ------------------------------------------------------------------ BN forward
-// ---- both reduction stages of a large statistics table in ONE launch.  grid (ceil(C / 64), G) x 512 threads: block (x, g) sums its row
-// group of the two tables for 64 columns into scratch[t][g][c] (double), takes a ticket for its column block, and the block that draws
-// the last one sums the G scratch rows IN ROW ORDER (deterministic whichever block it is) and finalizes.  Meant to save the second launch of
-// every BatchNorm with more than BN_SINGLE_STAGE_ROWS partial rows (~5 us of launch latency each, 40 per step); the fences cost far more
-// than that (see bn_tickets_for): kept as an experiment, MMSKIN_BN_FUSED_STAGES=1.
-// tickets[x] is zero before the launch and wraps back to zero with the last ticket (atomicInc); release / acquire at agent scope around the ticket
-// (__threadfence: L2 write-back / invalidate across the XCDs).
-struct BnStageSrc { const float* a0; const float* a1; size_t row_stride; };   // two tables with a common row stride (elements)
-__device__ __forceinline__ bool bn_stage1_and_ticket(const BnStageSrc src, int nrows, int C, int G, double* __restrict__ scratch, unsigned* tickets,
-                                                      double (*red)[8][64]) {
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  const int per = (nrows + G - 1) / G;
-  const int r0 = blockIdx.y * per, r1 = min(nrows, r0 + per);
-  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
-  if (c < C) {
-    int r = r0 + ry;
-    const size_t rs = src.row_stride;
-    for (; r + 24 < r1; r += 32) {
-      a0 += (double)src.a0[(size_t)r * rs + c]; b0 += (double)src.a1[(size_t)r * rs + c];
-      a1 += (double)src.a0[(size_t)(r + 8) * rs + c]; b1 += (double)src.a1[(size_t)(r + 8) * rs + c];
-      a2 += (double)src.a0[(size_t)(r + 16) * rs + c]; b2 += (double)src.a1[(size_t)(r + 16) * rs + c];
-      a3 += (double)src.a0[(size_t)(r + 24) * rs + c]; b3 += (double)src.a1[(size_t)(r + 24) * rs + c];
-    }
-    for (; r < r1; r += 8) { a0 += (double)src.a0[(size_t)r * rs + c]; b0 += (double)src.a1[(size_t)r * rs + c]; }
-  }
-  red[0][ry][cx] = (a0 + a1) + (a2 + a3); red[1][ry][cx] = (b0 + b1) + (b2 + b3);
-  __syncthreads();
-  if (ry == 0 && c < C) {
-    double s = 0, q = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s += red[0][i][cx]; q += red[1][i][cx]; }
-    scratch[(size_t)blockIdx.y * C + c] = s;
-    scratch[((size_t)G + blockIdx.y) * C + c] = q;
-  }
-  __threadfence();
-  __syncthreads();
-  __shared__ unsigned last;
-  if (threadIdx.x == 0) last = atomicInc(&tickets[blockIdx.x], (unsigned)(G - 1)) == (unsigned)(G - 1) ? 1u : 0u;   // wraps to 0 with the last ticket
-  __syncthreads();
-  if (!last) return false;
-  __threadfence();
-  // second stage: 8 lanes x 64 columns over the G scratch rows, then the lanes in order
-  double s = 0, q = 0;
-  if (c < C)
-    for (int g = ry; g < G; g += 8) { s += scratch[(size_t)g * C + c]; q += scratch[((size_t)G + g) * C + c]; }
-  red[0][ry][cx] = s; red[1][ry][cx] = q;
-  __syncthreads();
-  return true;
-}
-__global__ __launch_bounds__(512) void bn_finalize_two_stage_kernel(const BnStageSrc src, int nrows, int C, int G, double* __restrict__ scratch, unsigned* tickets,
-                                                                    double count, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                                                    float* save_mean, float* save_invstd) {
-  __shared__ double red[2][8][64];
-  if (!bn_stage1_and_ticket(src, nrows, C, G, scratch, tickets, red)) return;
-  const int cx = threadIdx.x & 63, c = blockIdx.x * 64 + cx;
-  if (threadIdx.x < 64 && c < C) {
-    double s = 0, q = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s += red[0][i][cx]; q += red[1][i][cx]; }
-    bn_fwd_coeffs(c, s, q, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
-  }
-}
-
-// one ticket row per stream that runs BatchNorm reductions (a plan's main and branch streams run them concurrently): library-owned,
-// zeroed once.  nullptr (more than 16 streams, or an allocation failure): the caller keeps the two-launch form.
-#include <mutex>
-static unsigned* bn_tickets_for(hipStream_t st) {
-  static std::mutex mu;
-  static unsigned* base = nullptr;
-  static hipStream_t owner[16];
-  static int n = 0;
-  // OFF by default: measured 19.17 vs 17.85 ms per ResNet-50 step (profiles/r04_experiments.txt (11)) -- every block's agent-scope fence
-  // writes back / invalidates its XCD's whole L2 while the other stream's kernels are filling it; 40 such launches cost 1.3 ms
-  static const int on = [] { const char* e = getenv("MMSKIN_BN_FUSED_STAGES"); return e ? atoi(e) : 0; }();
-  if (!on) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!base) {
-    if (hipMalloc(reinterpret_cast<void**>(&base), 16 * 64 * sizeof(unsigned)) != hipSuccess) { base = nullptr; return nullptr; }
-    if (hipMemset(base, 0, 16 * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
-  }
-  for (int i = 0; i < n; ++i)
-    if (owner[i] == st) return base + i * 64;
-  if (n == 16) return nullptr;
-  owner[n] = st;
-  return base + (n++) * 64;
-}
-
 template <typename IN, int RL = 4>
 __global__ __launch_bounds__(64 * RL) void bn_finalize_kernel(const IN* __restrict__ ssum, const IN* __restrict__ ssq, int nrows,
                                    int C, double count, const float* __restrict__ gamma,
@@ -290,12 +201,7 @@ int bn_finalize(const float* stat_sum, const float* stat_sq, int nrows, int C, d
                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                 float* running_var, float* scale, float* shift, float* save_mean, float* save_invstd,
                 double* scratch, hipStream_t st) {
-  unsigned* tickets = (scratch && nrows > BN_SINGLE_STAGE_ROWS && C <= 64 * 64) ? bn_tickets_for(st) : nullptr;
-  if (tickets) {
-    const int G = reduce_groups(nrows);
-    hipLaunchKernelGGL(bn_finalize_two_stage_kernel, dim3(ceil_div(C, 64), G), dim3(512), 0, st, BnStageSrc{stat_sum, stat_sq, (size_t)C}, nrows, C, G,
-                       scratch, tickets, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_invstd);
-  } else if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {   // (both stages in one launch behind a ticket per column block: +1.3 ms per step, profiles/r04_experiments.txt (11))
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(stat_sum, stat_sq, nrows, C, G, scratch, st);
     if (rc) return rc;
@@ -564,32 +470,12 @@ __global__ __launch_bounds__(CB * RL) void bn_bwd_finalize_kernel(const IN* __re
     bn_bwd_coeffs(c, s1, s2, count, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, s2_override);
   }
 }
-__global__ __launch_bounds__(512) void bn_bwd_finalize_two_stage_kernel(const BnStageSrc src, int nrows, int C, int G, double* __restrict__ scratch, unsigned* tickets,
-                                                                        double count, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                        const float* __restrict__ invstd, float* dgamma, float* dbeta, float* cA, float* cB,
-                                                                        float* cC, int n_grad, int acc_bc, const float* __restrict__ s2_override) {
-  __shared__ double red[2][8][64];
-  if (!bn_stage1_and_ticket(src, nrows, C, G, scratch, tickets, red)) return;
-  const int cx = threadIdx.x & 63, c = blockIdx.x * 64 + cx;
-  if (threadIdx.x < 64 && c < C) {
-    double s1 = 0, s2 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { s1 += red[0][i][cx]; s2 += red[1][i][cx]; }
-    bn_bwd_coeffs(c, s1, s2, count, gamma, mean, invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, s2_override);
-  }
-}
-
 int bn_bwd_finalize(const float* partial, int nrows, int C, double count, const float* gamma,
                     const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                     float* cA, float* cB, float* cC, double* scratch, hipStream_t st, int n_grad, bool accumulate_bc, const float* sum_dz_x) {
   if (n_grad < 0) n_grad = C;
   const int acc_bc = accumulate_bc ? 1 : 0;
-  unsigned* tickets = (scratch && nrows > BN_SINGLE_STAGE_ROWS && C <= 64 * 64) ? bn_tickets_for(st) : nullptr;
-  if (tickets) {   // the table's rows are [sum dz | sum dz x], 2 C wide
-    const int G = reduce_groups(nrows);
-    hipLaunchKernelGGL(bn_bwd_finalize_two_stage_kernel, dim3(ceil_div(C, 64), G), dim3(512), 0, st, BnStageSrc{partial, partial + C, (size_t)2 * C}, nrows,
-                       C, G, scratch, tickets, count, gamma, save_mean, save_invstd, dgamma, dbeta, cA, cB, cC, n_grad, acc_bc, sum_dz_x);
-  } else if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
+  if (scratch && nrows > BN_SINGLE_STAGE_ROWS) {
     const int G = reduce_groups(nrows);
     int rc = partial_reduce<double>(partial, nullptr, nrows, 2 * C, G, scratch, st);
     if (rc) return rc;

@@ -88,13 +88,11 @@ def test_conv_bf16_tight_on_representable_inputs(case):
     assert rec["wgrad"] < 1e-4, rec
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_batchnorm_two_stage_reduction_in_one_launch(fused):
-    """Statistics tables above MMSKIN_BN_SINGLE_ROWS rows take two reduction stages: one launch with a ticket per column block
-    (ops.hip bn_finalize_two_stage_kernel, MMSKIN_BN_FUSED_STAGES=1: an experiment, slower) or two launches (default).  MMSKIN_BN_SINGLE_ROWS=4 sends every
-    case of test_batchnorm_train_forward_backward through them, twelve launches in one process (the tickets wrap back to zero)."""
+def test_batchnorm_two_stage_reduction():
+    """Statistics tables above MMSKIN_BN_SINGLE_ROWS rows take two reduction stages (partial_reduce + finalize): MMSKIN_BN_SINGLE_ROWS=4 sends
+    every case of test_batchnorm_train_forward_backward through them."""
     import subprocess, sys
-    env = dict(os.environ, MMSKIN_BN_SINGLE_ROWS="4", MMSKIN_BN_FUSED_STAGES=fused)
+    env = dict(os.environ, MMSKIN_BN_SINGLE_ROWS="4")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k", "batchnorm_train_forward_backward"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
