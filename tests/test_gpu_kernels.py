@@ -421,6 +421,24 @@ def test_custom_cnn_pieces():
     _chk(out, ref); _chk(wd.grad, wr.grad, 1e-4); _chk(bd.grad, br.grad, 1e-4)
 
 
+def test_linear_rows_gives_whole_parameter_gradients():
+    """ops.linear_rows (value projection of nn.MultiheadAttention with one key): y and dx as F.linear on the row block, dW / db of the WHOLE
+    stacked parameter with exact zeros outside it -- what autograd's slice backward produces with two fills and two copies."""
+    g = torch.Generator().manual_seed(21)
+    D, B = 96, 37
+    x = torch.randn(B, D, generator=g)
+    W = torch.randn(3 * D, D, generator=g) / D ** 0.5
+    b = torch.randn(3 * D, generator=g)
+    dy = torch.randn(B, D, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    F.linear(xr, Wr[2 * D:], br[2 * D:]).backward(dy)
+    xd, Wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = ops.linear_rows(xd, Wd, bd, 2 * D, 3 * D)
+    y.backward(dy.to(DEV))
+    _chk(y, F.linear(x, W[2 * D:], b[2 * D:])); _chk(xd.grad, xr.grad); _chk(Wd.grad, Wr.grad, 1e-4); _chk(bd.grad, br.grad, 1e-4)
+    assert float(Wd.grad[:2 * D].abs().max()) == 0.0 and float(bd.grad[:2 * D].abs().max()) == 0.0
+
+
 def test_linear_bf16_operand_mode():
     """MMSKIN_LINEAR_DTYPE=bf16: Linear layers over batch x tokens rows run on the bf16 MFMA kernels (fp32 accumulate,
     fp32 tensors at the boundary).  Checked in a fresh process (the mode is read once) against torch on bf16-rounded inputs."""
