@@ -179,13 +179,15 @@ __global__ __launch_bounds__(64 * RL) void bn_finalize_kernel(const IN* __restri
   double s = 0.0, q = 0.0;
   if (c < C) {
     int r = ry;
-    double s1 = 0.0, q1 = 0.0;
-    for (; r + RL < nrows; r += 2 * RL) {     // two independent chains per lane
+    double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+    for (; r + 3 * RL < nrows; r += 4 * RL) {     // four independent chains per lane (eight loads in flight)
       s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c];
       s1 += (double)ssum[(size_t)(r + RL) * C + c]; q1 += (double)ssq[(size_t)(r + RL) * C + c];
+      s2 += (double)ssum[(size_t)(r + 2 * RL) * C + c]; q2 += (double)ssq[(size_t)(r + 2 * RL) * C + c];
+      s3 += (double)ssum[(size_t)(r + 3 * RL) * C + c]; q3 += (double)ssq[(size_t)(r + 3 * RL) * C + c];
     }
-    if (r < nrows) { s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c]; }
-    s += s1; q += q1;
+    for (; r < nrows; r += RL) { s += (double)ssum[(size_t)r * C + c]; q += (double)ssq[(size_t)r * C + c]; }
+    s = (s + s1) + (s2 + s3); q = (q + q1) + (q2 + q3);
   }
   red[0][ry][cx] = s; red[1][ry][cx] = q;
   __syncthreads();
@@ -451,15 +453,19 @@ __global__ __launch_bounds__(CB * RL) void bn_bwd_finalize_kernel(const IN* __re
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
     int r = ry;
-    double t1 = 0.0, t2 = 0.0;
-    for (; r + RL < nrows; r += 2 * RL) {     // two independent chains per lane
+    double t1 = 0.0, t2 = 0.0, u1 = 0.0, u2 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (; r + 3 * RL < nrows; r += 4 * RL) {     // four independent chains per lane (eight loads in flight)
       s1 += (double)partial[((size_t)r * 2) * C + c];
       s2 += (double)partial[((size_t)r * 2 + 1) * C + c];
       t1 += (double)partial[((size_t)(r + RL) * 2) * C + c];
       t2 += (double)partial[((size_t)(r + RL) * 2 + 1) * C + c];
+      u1 += (double)partial[((size_t)(r + 2 * RL) * 2) * C + c];
+      u2 += (double)partial[((size_t)(r + 2 * RL) * 2 + 1) * C + c];
+      v1 += (double)partial[((size_t)(r + 3 * RL) * 2) * C + c];
+      v2 += (double)partial[((size_t)(r + 3 * RL) * 2 + 1) * C + c];
     }
-    if (r < nrows) { s1 += (double)partial[((size_t)r * 2) * C + c]; s2 += (double)partial[((size_t)r * 2 + 1) * C + c]; }
-    s1 += t1; s2 += t2;
+    for (; r < nrows; r += RL) { s1 += (double)partial[((size_t)r * 2) * C + c]; s2 += (double)partial[((size_t)r * 2 + 1) * C + c]; }
+    s1 = (s1 + t1) + (u1 + v1); s2 = (s2 + t2) + (u2 + v2);
   }
   red[0][ry][cx] = s1; red[1][ry][cx] = s2;
   __syncthreads();
