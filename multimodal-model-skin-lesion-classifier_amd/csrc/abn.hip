@@ -123,13 +123,16 @@ __global__ __launch_bounds__(256) void gram_stats_kernel(const float* __restrict
   const float wk = abn_wb(W[(size_t)o * Cw + k]);
   wrow[k] = wk;
   __syncthreads();
-  double t0 = 0.0, t1 = 0.0;
-  for (int k2 = 0; k2 < Cw; k2 += 2) {
-    t0 += (double)wrow[k2] * (double)Gm[(size_t)k2 * Cw + k];
-    t1 += (double)wrow[k2 + 1] * (double)Gm[(size_t)(k2 + 1) * Cw + k];
+  double t[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // eight independent loads in flight (Cw % 8 == 0; two chains took 10 us)
+  for (int k2 = 0; k2 < Cw; k2 += 8) {
+    float gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = Gm[(size_t)(k2 + e) * Cw + k];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] += (double)wrow[k2 + e] * (double)gv[e];
   }
   red[0][k] = (double)wk * (double)colsum[k];
-  red[1][k] = (double)wk * (t0 + t1);
+  red[1][k] = (double)wk * (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])));
   __syncthreads();
   for (int s = Cw >> 1; s > 0; s >>= 1) {
     if (k < s) { red[0][k] += red[0][k + s]; red[1][k] += red[1][k + s]; }
