@@ -11,7 +11,8 @@ dev = "cuda:0"
 model = M.MultimodalModel(num_classes=6, num_heads=8, device=dev, cnn_model_name="resnet-50", text_model_name="one-hot-encoder", common_dim=512,
                           vocab_size=20, unfreeze_weights="unfrozen_weights", attention_mecanism="crossattention").to(dev)
 model.train()
-opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)
+from mmskin.optim import Adam
+opt = Adam(model.parameters(), lr=5e-5, weight_decay=1e-4, fused=True)   # as bench.py
 crit = nn.CrossEntropyLoss()
 img = torch.randn(256, 3, 224, 224, device=dev); meta = torch.randn(256, 20, device=dev); lab = torch.randint(0, 6, (256,), device=dev)
 bb = model.image_encoder
