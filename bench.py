@@ -483,6 +483,10 @@ def main():
                     "traffic": traffic, "traffic_note": traffic_note, "launches_per_step": int(n_launch),
                     "algorithmic_gbytes_per_launch": round(dom_by / max(n_launch, 1) / 1e9, 4),
                     "algorithmic_gbps": round(dom_by / (dom_ms * 1e-3) / 1e9, 1),
+                    # the same launches against the OTHER roof (their algorithmic bytes exceed what their FLOPs take at peak: hbm_floor_ms >
+                    # mfma_floor_ms): algorithmic bytes per launch / launch time over the 8 TB/s HBM3E peak
+                    "frac_hbm_isolated": round(dom_by / (dom_ms * 1e-3) / 8.0e12, 4),
+                    "frac_hbm_production": (round(dom_by / max(n_launch, 1) / (prod_us * 1e-6) / 8.0e12, 4) if prod_us else None),
                     "hbm_floor_ms": round(dom_by / 6.3e12 * 1e3, 3), "mfma_floor_ms": round(dom_fl / (peak * 1e12) * 1e3, 3),
                     "measured_ms": round(dom_ms, 3),
                     "avg_launch_us": round(dom_ms * 1e3 / max(n_launch, 1), 2),
