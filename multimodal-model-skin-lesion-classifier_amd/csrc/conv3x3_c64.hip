@@ -172,11 +172,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(const C3Args p) {
       fa[buf][f][ks] = *reinterpret_cast<const uint4*>(ra[f][TAP_OY(t) + 1] + (TAP_OX(t) + 1) * PITCH + ks * 64);         \
   }
     READ_TAP(0, 0)
+    // EPI 3: the consumer unit's raw BatchNorm input of this tile, fetched behind the LAST tap's fragment reads (the other fragment buffer is
+    // dead by then: no extra registers) instead of in the epilogue, where every fragment waited a full memory round trip for its 16 bytes
+    uint4 xpre[EPI == 3 ? FH : 1];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int cur = t & 1;
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < 9) { READ_TAP(cur ^ 1, t + 1) }
+      if constexpr (EPI == 3) {
+        if (t == 8) {
+#pragma unroll
+          for (int f = 0; f < FH; ++f) {
+            const size_t offx = (((size_t)n * H + ybase) * W + 16 * (FH * a + f) + l15) * 64 + ch0;
+            xpre[f] = *reinterpret_cast<const uint4*>(p.ep_x + offx);
+          }
+        }
+      }
       if (!(abl & 4))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(const C3Args p) {
       float v[8] = {acc[f][0][0], acc[f][0][1], acc[f][0][2], acc[f][0][3], acc[f][1][0], acc[f][1][1], acc[f][1][2], acc[f][1][3]};
       float xv[8];
       if constexpr (EPI == 3) {
-        const uint4 xr = *reinterpret_cast<const uint4*>(p.ep_x + off);
+        const uint4 xr = xpre[f];
         const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xv[2 * e] = __uint_as_float(xw[e] << 16); xv[2 * e + 1] = __uint_as_float(xw[e] & 0xffff0000u); }
